@@ -1,0 +1,202 @@
+/*
+ * vfdgan_hip.h — C ABI of libvfdgan_hip.so, the MI355X (gfx950) device library behind the
+ * video-GAN training step of umaionigiri/vfd_gan.
+ *
+ * The reference has no FFI: its boundary to the arithmetic is the torch.nn call sites on the hot
+ * path (reference paths relative to /root/reference, cited per entry point below).  Each entry point
+ * replaces the ATen/cuDNN kernel(s) behind one such call site.  All pointers are DEVICE pointers
+ * unless noted; tensors are dense "channels-last" blocks
+ *
+ *      act[N][D][H][W][Cp]      Cp = VFD_CPAD(C) = C rounded up to a multiple of 8,
+ *                               pad channels hold zeros (2-D nets use D = 1)
+ *
+ * in `dtype` VFD_F32 (float) or VFD_BF16 (bfloat16 bit patterns in uint16_t).  Every function is
+ * asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream), allocates
+ * nothing, synchronises nothing and is therefore hipGraph-capturable.  Return value: 0 on success,
+ * a negative VFD_E* code otherwise (message via vfd_last_error()).  No global mutable state other
+ * than the thread-local error string.
+ */
+#ifndef VFDGAN_HIP_H
+#define VFDGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFD_ABI_VERSION 1
+
+#define VFD_F32 0
+#define VFD_BF16 1
+
+#define VFD_OK 0
+#define VFD_EINVAL (-1)   /* bad argument (shape/dtype/alignment) */
+#define VFD_ELAUNCH (-2)  /* hipLaunch / hipGetLastError failure */
+#define VFD_ENOSPACE (-3) /* workspace too small */
+
+#define VFD_CPAD(c) (((c) + 7) & ~7)
+
+/* activation codes (fused epilogues and element-wise ops) */
+#define VFD_ACT_NONE 0
+#define VFD_ACT_LRELU 1   /* x>0 ? x : slope*x ; slope 0 = ReLU; slope may exceed 1 (anogan.py:91 uses 64) */
+#define VFD_ACT_SIGMOID 2
+#define VFD_ACT_TANH 3
+
+int vfd_abi_version(void);
+const char* vfd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout / dtype conversion at the boundary.
+ * The reference hands (N,C,T,H,W) float32 tensors to the nets (lib/train_gan.py:69,
+ * models/mygannet.py:275-286); 2-D ganomaly takes (N,C,H,W) (models/ganomaly.py:444).
+ * ---------------------------------------------------------------------------------------------- */
+/* src float32 [N][C][S] (S = D*H*W)  ->  dst dtype [N][S][Cp], pad channels zeroed. */
+int vfd_ncs_to_nsc(int dtype, const float* src, void* dst, int64_t N, int C, int64_t S, void* stream);
+/* src dtype [N][S][Cp] -> dst float32 [N][C][S] (pad channels dropped).                          */
+int vfd_nsc_to_ncs(int dtype, const void* src, float* dst, int64_t N, int C, int64_t S, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution family: nn.Conv3d / nn.ConvTranspose3d / nn.Conv2d / nn.ConvTranspose2d / nn.Linear
+ *   models/anogan.py:44,51-52,56-57,64-65,69-70,85,88-89,96-97,101,108
+ *   models/mygannet.py:52,134,176 ; models/spatiotempconv.py:49-50,59-60
+ *   models/ganomaly.py:37,45,54,66,96,105,116,123
+ * One implicit-GEMM kernel family on MFMA (bf16: v_mfma_f32_16x16x32_bf16, f32: v_mfma_f32_16x16x4_f32).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vfd_conv_desc {
+  int32_t N;
+  int32_t Di, Hi, Wi, Cin;  /* input block  [N][Di][Hi][Wi][CPAD(Cin)]  */
+  int32_t Do, Ho, Wo, Cout; /* output block [N][Do][Ho][Wo][CPAD(Cout)] */
+  int32_t kd, kh, kw;       /* filter taps  */
+  int32_t sd, sh, sw;       /* stride       */
+  int32_t pd, ph, pw;       /* zero padding */
+  int32_t transposed;       /* 0: out[o] = sum_k in[o*s-p+k] w[k]  (nn.ConvNd)
+                               1: out[o] = sum_k in[(o+p-k)/s] w[k] (nn.ConvTransposeNd; Do.. given by caller,
+                                  which encodes output_padding)                                            */
+  int32_t dtype;            /* VFD_F32 | VFD_BF16: element type of in, out and packed filter; accumulate f32 */
+  int32_t act;              /* VFD_ACT_* fused into the epilogue (after bias)                               */
+  float slope;              /* LRELU slope                                                                  */
+} vfd_conv_desc;
+
+/* Filter packing.  A torch filter is float32 w[A][B][T] (A,B channel dims, T = kd*kh*kw taps, row-major).
+ * The kernel wants rows of GEMM-K:  packed[R][T][CPAD(Cc)]  (R = output channel of the GEMM, Cc = contracted).
+ *   transpose_ab = 0 : R = A, Cc = B   packed[a][t][b] = w[a][b][t]   (Conv forward; ConvTranspose dgrad)
+ *   transpose_ab = 1 : R = B, Cc = A   packed[b][t][a] = w[a][b][t]   (ConvTranspose forward; Conv dgrad)   */
+int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T, int transpose_ab,
+                    void* stream);
+
+/* y = act(conv(x, packed) + bias).  `bias` float32[Cout] or NULL.
+ * When stats != NULL (float32 [2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates the per-channel
+ * sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
+ * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106).                  */
+int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
+                     float* stats, void* stream);
+
+/* Filter gradient.  Computes, for the conv described by `d` (same desc as forward),
+ *     dWp[r][t][c] = sum_{n,q} S[n,q][r] * G[n, q*s-p+t][c]
+ * with (S,G) = (dy, x) for transposed = 0 and (x, dy) for transposed = 1, i.e. in the packed layout of
+ * vfd_pack_filter(transpose_ab = 0) over the torch filter w[A][B][T] with A = channels of S, B = channels of G.
+ * The reduction over pixels is split `nsplit` ways into float32 slabs ws[nsplit][A][T*CPAD(B)]; call
+ * vfd_wgrad_workspace() for nsplit and the byte size, then vfd_wgrad_reduce() to fold the slabs into the
+ * torch-layout gradient dw[A][B][T] (dw = beta*dw + sum).  Also returns the bias gradient when db != NULL:
+ * db[c] = beta*db[c] + sum over pixels of dy[..][c].                                                       */
+int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes);
+int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
+                   void* stream);
+int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream);
+int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (training mode) fused with the activation that follows it.
+ *   nn.BatchNorm3d/2d/1d + LeakyReLU/ReLU: models/mygannet.py:19-20,109-110; models/spatiotempconv.py:51-52;
+ *   models/anogan.py:45-46,53-54,58-59,66-67,86-87,90-91,98-99,102-103; models/ganomaly.py:46-49,56-59,97-100,106-109
+ * x is [rows][Cp]; statistics are over rows (biased variance for normalisation, unbiased for running_var).
+ * ---------------------------------------------------------------------------------------------- */
+/* partial[blocks][3][Cp] workspace reduction -> mean[Cp], rstd[Cp]; updates running stats when non-NULL:
+ * running = (1-momentum)*running + momentum*batch (unbiased var).  ws must hold vfd_bn_workspace() bytes. */
+size_t vfd_bn_workspace(int64_t rows, int C);
+int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float momentum, float* mean,
+                 float* rstd, float* running_mean, float* running_var, void* ws, void* stream);
+/* Same, from the conv epilogue's sum / sum-of-squares buffer (stats[2][Cp]).                              */
+int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean,
+                           float* rstd, float* running_mean, float* running_var, void* stream);
+/* y = act((x-mean)*rstd*gamma + beta) */
+int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, int act, float slope,
+                       void* stream);
+/* Backward: g = dy*act'(.), dgamma = sum g*xhat, dbeta = sum g,
+ * dx = gamma*rstd*(g - dbeta/rows - xhat*dgamma/rows).  dgamma/dbeta are OVERWRITTEN.                     */
+int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C,
+                        const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                        float slope, float* dgamma, float* dbeta, void* ws, void* stream);
+
+/* Element-wise activation and its backward from the OUTPUT (all supported activations are invertible in
+ * sign / expressible from y): dx = dy * act'(y).                                                          */
+int vfd_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, int act, float slope, void* stream);
+int vfd_act_backward(int dtype, const void* y, const void* dy, void* dx, int64_t rows, int C, int act,
+                     float slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling / resampling / channel plumbing.
+ *   nn.AvgPool3d: models/mygannet.py:41,132-133,174-175; models/anogan.py:92,100,104
+ *   nn.Upsample(scale 2, trilinear, align_corners=True): models/mygannet.py:50
+ *   torch.cat(dim=1): models/mygannet.py:79,84,89,94 ; gray2rgb: lib/utils.py:91-92
+ *   nn.Dropout(p): models/mygannet.py:49 ; models/anogan.py:50,55,63,68
+ * ---------------------------------------------------------------------------------------------- */
+int vfd_avgpool_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, int kd, int kh,
+                        int kw, void* stream);
+int vfd_avgpool_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C, int kd,
+                         int kh, int kw, void* stream);
+int vfd_upsample2x_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
+int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C,
+                            void* stream);
+/* dst[rows][CPAD(Ca+Cb)] = concat(a[rows][CPAD(Ca)], b[rows][CPAD(Cb)]) ; split is the backward.         */
+int vfd_concat_channels(int dtype, const void* a, const void* b, void* dst, int64_t rows, int Ca, int Cb,
+                        void* stream);
+int vfd_split_channels(int dtype, const void* src, void* a, void* b, int64_t rows, int Ca, int Cb,
+                       void* stream);
+/* dst[rows][CPAD(reps)] = src[rows][CPAD(1)] channel 0 broadcast to `reps` channels (gray2rgb).            */
+int vfd_broadcast_channel(int dtype, const void* src, void* dst, int64_t rows, int reps, void* stream);
+/* y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based generator keyed by (seed, element).
+ * mask (uint8 [n]) is written for the backward; pass mask_in != NULL to impose a mask (parity tests).     */
+int vfd_dropout_forward(int dtype, const void* x, void* y, uint8_t* mask_out, const uint8_t* mask_in,
+                        int64_t n, float p, uint64_t seed, void* stream);
+int vfd_dropout_backward(int dtype, const void* dy, void* dx, const uint8_t* mask, int64_t n, float p,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses (mean reductions) on [rows][CPAD(C)] blocks; pad channels are ignored.  `b` may be NULL, then the
+ * target is the constant `bconst` (the ones / zeros labels of models/mygannet.py:258-261,
+ * models/anogan.py:142-143, models/ganomaly.py:449-450).
+ *   l2_loss        lib/utils.py:59-63     mean((a-b)^2)
+ *   nn.L1Loss      models/ganomaly.py:438 mean(|a-b|)
+ *   nn.BCELoss     models/mygannet.py:267, models/anogan.py:138, models/ganomaly.py:440 (log clamped at -100)
+ *   weighted_bce   lib/utils.py:65-71     clamp(a,1e-8,1-1e-8); -mean(b log a + pw (1-b) log(1-a))
+ * forward : *loss (ONE float32 on the device) is overwritten; deterministic two-stage reduction through ws.
+ * backward: grad_a / grad_b (either may be NULL) = scale * (*gout) * dLoss/d{a,b}; gout is a DEVICE scalar
+ *           (the incoming autograd gradient) or NULL (= 1), so no host sync sits between loss and backward.
+ * ---------------------------------------------------------------------------------------------- */
+#define VFD_LOSS_L2 0
+#define VFD_LOSS_L1 1
+#define VFD_LOSS_BCE 2
+#define VFD_LOSS_WBCE 3
+size_t vfd_loss_workspace(int64_t rows, int C);
+int vfd_loss_forward(int kind, int dtype, const void* a, const void* b, float bconst, float* loss, int64_t rows,
+                     int C, float pos_weight, void* ws, void* stream);
+int vfd_loss_backward(int kind, int dtype, const void* a, const void* b, float bconst, const float* gout,
+                      void* grad_a, void* grad_b, int64_t rows, int C, float scale, float pos_weight,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optim.Adam (models/mygannet.py:270-273, models/anogan.py:139-140, models/ganomaly.py:455-456):
+ * eps 1e-8, no weight decay, no amsgrad, bias-corrected; one launch over a flat float32 arena.
+ * grad_scale multiplies the gradient first (1/world_size for data-parallel sums).
+ * ---------------------------------------------------------------------------------------------- */
+int vfd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFDGAN_HIP_H */

@@ -1,0 +1,247 @@
+"""GPU parity of every HIP primitive against the torch CPU float32 op the reference calls (SURVEY.md 2.1 K1-K6,
+E1-E6, L1, O1), at odd shapes (Cout=21, T=1, H=7 ...), through the C ABI (ctypes) only."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from util import TOL, relerr
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # name, x shape (N,C,D,H,W) or (N,C,H,W), Cout, k, s, p, op, transposed, bias
+    ("K1_3x3x3", (2, 5, 4, 9, 7), 21, 3, 1, 1, 0, False, True),
+    ("K1_big", (1, 64, 3, 12, 12), 72, 3, 1, 1, 0, False, True),
+    ("K2_1x3x3", (2, 3, 3, 10, 10), 21, (1, 3, 3), 1, (0, 1, 1), 0, False, True),
+    ("K3_3x1x1", (2, 21, 5, 6, 6), 32, (3, 1, 1), 1, (1, 0, 0), 0, False, True),
+    ("K4_1x1x1", (2, 14, 2, 5, 5), 3, 1, 1, 0, 0, False, True),
+    ("K5_convT_s2", (2, 12, 2, 5, 6), 9, 3, 2, 1, 1, True, True),
+    ("K5_convT_s1", (1, 16, 3, 6, 6), 8, 3, 1, 1, 0, True, True),
+    ("K6_conv2d_k4s2", (3, 3, 16, 16), 16, 4, 2, 1, 0, False, False),
+    ("K6_conv2d_k4s2_wide", (2, 40, 14, 14), 136, 4, 2, 1, 0, False, False),
+    ("K6_conv2d_final_k7", (5, 24, 7, 7), 100, 7, 1, 0, 0, False, False),
+    ("K6_convT2d_init_k7", (5, 100, 1, 1), 24, 7, 1, 0, 0, True, False),
+    ("K6_convT2d_k4s2", (2, 24, 7, 7), 12, 4, 2, 1, 0, True, False),
+    ("K6_convT2d_to3", (2, 16, 8, 8), 3, 4, 2, 1, 0, True, False),
+    ("K6_conv2d_extra_k3", (2, 16, 8, 8), 16, 3, 1, 1, 0, False, False),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_family(case, dt, dev):
+    from vfd_gan_amd import functional as F
+    name, xs, cout, k, s, p, op, tr, has_bias = case
+    nd = len(xs) - 2
+    cin = xs[1]
+    kk = (k,) * nd if isinstance(k, int) else k
+    wshape = ((cin, cout) if tr else (cout, cin)) + tuple(kk)
+    x = _rand(xs, 1)
+    w = _rand(wshape, 2, 0.2)
+    b = _rand((cout,), 3, 0.5) if has_bias else None
+    if dt == torch.bfloat16:  # compare against the same bf16-rounded operands (products are then exact in f32)
+        x = x.bfloat16().float()
+        w = w.bfloat16().float()
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if has_bias else None
+    fn = {(2, False): TF.conv2d, (3, False): TF.conv3d, (2, True): TF.conv_transpose2d, (3, True): TF.conv_transpose3d}[(nd, tr)]
+    yr = fn(xr, wr, br, s, p, op) if tr else fn(xr, wr, br, s, p)
+    gy = _rand(tuple(yr.shape), 4)
+    if dt == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    yr.backward(gy)
+
+    xd = x.to(dev).requires_grad_()
+    wd = torch.nn.Parameter(w.to(dev))
+    bd = torch.nn.Parameter(b.to(dev)) if has_bias else None
+    xc = F.to_cl(xd, dt)
+    yc = F.conv(xc, wd, bd, s, p, op, tr)
+    y = yc.to_torch()
+    assert tuple(y.shape) == tuple(yr.shape)
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    tol = TOL[dt]
+    assert relerr(y, yr) < tol, ("fwd", relerr(y, yr))
+    assert relerr(xd.grad, xr.grad) < tol, ("dgrad", relerr(xd.grad, xr.grad))
+    assert relerr(wd.grad, wr.grad) < tol, ("wgrad", relerr(wd.grad, wr.grad))
+    if has_bias:
+        assert relerr(bd.grad, br.grad) < tol, ("bgrad", relerr(bd.grad, br.grad))
+    # pad channels of the raw block stay zero
+    assert float(yc.t[..., yc.C:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_conv_fused_act_and_stats(dt, dev):
+    from vfd_gan_amd import _lib, functional as F
+    x = _rand((2, 6, 3, 8, 8), 11)
+    w = _rand((13, 6, 3, 3, 3), 12, 0.3)
+    b = _rand((13,), 13)
+    if dt == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    pre = TF.conv3d(x, w, b, 1, 1)
+    for act, slope, ref in [(_lib.ACT_LRELU, 0.2, TF.leaky_relu(pre, 0.2)), (_lib.ACT_SIGMOID, 0.0, torch.sigmoid(pre)),
+                            (_lib.ACT_TANH, 0.0, torch.tanh(pre)), (_lib.ACT_LRELU, 64.0, TF.leaky_relu(pre, 64.0))]:
+        sums = torch.zeros(2 * 16, device=dev)
+        yc = F.conv(F.to_cl(x.to(dev), dt), torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)), 1, 1, 0, False, act,
+                    slope, stats=sums)
+        assert relerr(yc.to_torch(), ref) < TOL[dt]
+        s1 = pre.sum(dim=(0, 2, 3, 4))
+        s2 = (pre * pre).sum(dim=(0, 2, 3, 4))
+        assert relerr(sums[:13], s1) < 1e-4 and relerr(sums[16:29], s2) < 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape,act,slope", [((4, 21, 3, 5, 7), 1, 0.2), ((6, 8, 1, 9, 9), 1, 0.0), ((3, 130, 2, 4, 4), 1, 64.0),
+                                             ((16, 40), 1, 0.0), ((2, 5, 2, 3, 3), 0, 0.0), ((2, 5, 2, 3, 3), 3, 0.0)])
+def test_bn_act(shape, act, slope, dt, dev):
+    from vfd_gan_amd import functional as F
+    C = shape[1]
+    x = _rand(shape, 21, 2.0) + 0.7
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    gamma, beta = _rand((C,), 22) + 1.5, _rand((C,), 23)
+    rm, rv = _rand((C,), 24), _rand((C,), 25).abs() + 0.5
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rmr, rvr = rm.clone(), rv.clone()
+    z = TF.batch_norm(xr, rmr, rvr, gr, br, True, 0.1, 1e-5)
+    yr = {0: lambda t: t, 1: lambda t: TF.leaky_relu(t, slope), 3: torch.tanh}[act](z)
+    gy = _rand(shape, 26)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_()
+    gd, bd = torch.nn.Parameter(gamma.to(dev)), torch.nn.Parameter(beta.to(dev))
+    rmd, rvd = rm.to(dev), rv.to(dev)
+    y = F.bn_act(F.to_cl(xd, dt), gd, bd, rmd, rvd, 1e-5, 0.1, act, slope).to_torch()
+    y.backward(gy.to(dev))
+    tol = TOL[dt] * (4 if dt == torch.float32 else 1)
+    assert relerr(y, yr) < tol
+    assert relerr(rmd, rmr) < 1e-5 and relerr(rvd, rvr) < 1e-5
+    btol = 5e-2 if dt == torch.bfloat16 else 2e-4
+    assert relerr(xd.grad, xr.grad) < btol
+    assert relerr(gd.grad, gr.grad) < btol and relerr(bd.grad, br.grad) < btol
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_pool_upsample_concat_dropout(dt, dev):
+    from vfd_gan_amd import functional as F
+    tol = TOL[dt]
+    x = _rand((2, 11, 4, 6, 8), 31)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    for k in [(2, 2, 2), (1, 2, 2), (2, 1, 1), (4, 1, 1), (1, 6, 8)]:
+        xr = x.clone().requires_grad_()
+        yr = TF.avg_pool3d(xr, k)
+        gy = _rand(tuple(yr.shape), 32)
+        yr.backward(gy)
+        xd = x.to(dev).requires_grad_()
+        y = F.avg_pool(F.to_cl(xd, dt), k).to_torch()
+        y.backward(gy.to(dev))
+        assert relerr(y, yr) < tol and relerr(xd.grad, xr.grad) < tol
+    for shp in [(2, 11, 4, 6, 8), (1, 3, 1, 2, 5)]:
+        x2 = _rand(shp, 33)
+        xr = x2.clone().requires_grad_()
+        yr = TF.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True)
+        gy = _rand(tuple(yr.shape), 34)
+        yr.backward(gy)
+        xd = x2.to(dev).requires_grad_()
+        y = F.upsample_trilinear2x(F.to_cl(xd, dt)).to_torch()
+        y.backward(gy.to(dev))
+        assert relerr(y, yr) < tol * 2 and relerr(xd.grad, xr.grad) < tol * 4
+    for ca, cb in [(8, 16), (5, 3), (11, 21)]:
+        a, b = _rand((2, ca, 2, 3, 3), 35), _rand((2, cb, 2, 3, 3), 36)
+        ar, br_ = a.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = torch.cat([ar, br_], 1)
+        gy = _rand(tuple(yr.shape), 37)
+        yr.backward(gy)
+        ad, bd = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+        y = F.cat_channels(F.to_cl(ad, dt), F.to_cl(bd, dt)).to_torch()
+        y.backward(gy.to(dev))
+        assert relerr(y, yr) < tol and relerr(ad.grad, ar.grad) < tol and relerr(bd.grad, br_.grad) < tol
+    g1 = _rand((2, 1, 3, 4, 4), 38)
+    assert relerr(F.gray2rgb(F.to_cl(g1.to(dev), dt)).to_torch(), torch.cat([g1] * 3, 1)) < tol
+    # dropout: imposed mask reproduces x*mask/(1-p); generated mask has the right rate and is reused in backward
+    xm = _rand((2, 5, 2, 4, 4), 39)
+    mask = (torch.rand(xm.shape, generator=torch.Generator().manual_seed(5)) > 0.25)
+    F.set_dropout_mask_provider(lambda shape, p, i: mask)
+    xd = xm.to(dev).requires_grad_()
+    y = F.dropout(F.to_cl(xd, dt), 0.25).to_torch()
+    y.backward(torch.ones_like(y))
+    F.set_dropout_mask_provider(None)
+    assert relerr(y, xm * mask / 0.75) < tol and relerr(xd.grad, mask.float() / 0.75) < tol
+    big = torch.ones(4, 8, 4, 16, 16, device=dev)
+    yb = F.dropout(F.to_cl(big, dt), 0.25).to_torch()
+    rate = float((yb == 0).float().mean())
+    assert abs(rate - 0.25) < 0.01
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_losses(dt, dev):
+    from vfd_gan_amd import functional as F
+    from vfd_oracle.losses import l2_loss, weighted_bce
+    # known-answer tests of SURVEY.md 8(c)
+    a = torch.tensor([.2, .9, .5]).view(1, 3, 1, 1)
+    b = torch.tensor([0., 1., 1.]).view(1, 3, 1, 1)
+    ac, bc = F.to_cl(a.to(dev), torch.float32), F.to_cl(b.to(dev), torch.float32)
+    assert abs(float(F.l2_loss(ac, bc)) - 0.1) < 1e-7
+    assert abs(float(F.weighted_bce(ac, bc)) - 0.41493162) < 1e-6
+    assert abs(float(F.bce_loss(ac, bc)) - 0.34055042) < 1e-6
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    shape = (3, 5, 2, 6, 6)
+    p = torch.sigmoid(_rand(shape, 41, 3.0))
+    t = (_rand(shape, 42) > 0.6).float()
+    q = _rand(shape, 43)
+    if dt == torch.bfloat16:
+        p, q = p.bfloat16().float(), q.bfloat16().float()
+    cases = [("l2", F.l2_loss, l2_loss, p, q), ("l1", F.l1_loss, torch.nn.L1Loss(), p, q),
+             ("bce", F.bce_loss, torch.nn.BCELoss(), p, t), ("wbce", F.weighted_bce, weighted_bce, p, t)]
+    for name, fh, fr, u, v in cases:
+        ur, vr = u.clone().requires_grad_(), v.clone().requires_grad_(name in ("l2", "l1"))
+        lr = fr(ur, vr) * 3.0
+        lr.backward()
+        ud = u.to(dev).requires_grad_()
+        vd = v.to(dev).requires_grad_(name in ("l2", "l1"))
+        lh = fh(F.to_cl(ud, dt), F.to_cl(vd, dt)) * 3.0
+        lh.backward()
+        assert abs(float(lh) - float(lr)) < tol * max(1.0, abs(float(lr))), name
+        assert relerr(ud.grad, ur.grad) < max(tol, TOL[dt]), name
+        if name in ("l2", "l1"):
+            assert relerr(vd.grad, vr.grad) < max(tol, TOL[dt]), name
+    # constant-label BCE (ones / zeros labels of the GAN step)
+    pr = torch.sigmoid(_rand((7, 1), 44, 2.0))
+    for lab in (1.0, 0.0):
+        prr = pr.clone().requires_grad_()
+        lr = torch.nn.BCELoss()(prr.view(-1), torch.full((7,), lab))
+        lr.backward()
+        pd = pr.to(dev).requires_grad_()
+        lh = F.bce_loss(F.to_cl(pd, torch.float32), lab)
+        lh.backward()
+        assert abs(float(lh) - float(lr)) < 1e-6 and relerr(pd.grad, prr.grad) < 1e-5
+
+
+def test_adam_matches_torch(dev):
+    from vfd_gan_amd import optim as hoptim
+    torch.manual_seed(0)
+    ps = [torch.randn(33, 7), torch.randn(5), torch.randn(4, 3, 3, 3)]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+    o_hip = hoptim.Adam(mine, lr=2e-4, betas=(0.5, 0.999))
+    for it in range(4):
+        gs = [torch.randn_like(p) * (0.1 + it) for p in ps]
+        o_ref.zero_grad()
+        o_hip.zero_grad()
+        for p, g in zip(ref, gs):
+            p.grad = g.clone()
+        for p, g in zip(mine, gs):
+            p.grad.copy_(g.to(dev))
+        o_ref.step()
+        o_hip.step()
+    for a, b in zip(mine, ref):
+        assert relerr(a, b) < 1e-6

@@ -1,0 +1,13 @@
+import torch
+
+
+def relerr(a, b):
+    """max |a-b| / (max |b| + tiny) on float64 CPU copies."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# stated tolerances (max-norm relative error per tensor)
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2.5e-2}

@@ -1,0 +1,353 @@
+// Training-mode BatchNorm fused with the activation that follows it, on channels-last blocks [rows][Cp].
+// HBM-bound: forward = 1 read (statistics) + 1 read + 1 write (normalise+activate); the statistics read
+// disappears when the producing convolution accumulates sum / sum-of-squares in its epilogue.
+// Backward = 2 reads (reduce) + 2 reads + 1 write (apply).
+//
+// Thread layout for every kernel here: a workgroup is TX granule-lanes x TY row-lanes (TX*TY = 256); a thread
+// owns ONE granule (8 channels, 16/32 bytes) and walks rows, so per-channel parameters are loaded once.
+// Reductions are two-stage and deterministic: workgroup partials in a workspace, then a finalize kernel.
+#include "common.hpp"
+
+namespace {
+
+struct Tiling {
+  int TX, TY, gx, gy;
+  long long rows_per_block;
+};
+static Tiling make_tiling(long long rows, int C, int max_gy) {
+  Tiling t;
+  const int GR = cpad(C) >> 3;
+  int tx = 1;
+  while (tx < GR && tx < 256) tx <<= 1;
+  t.TX = tx; t.TY = 256 / tx;
+  t.gx = (GR + tx - 1) / tx;
+  long long gy = (rows + (long long)t.TY * 8 - 1) / ((long long)t.TY * 8);
+  const long long cap = max_gy / t.gx > 0 ? max_gy / t.gx : 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  t.gy = (int)gy;
+  t.rows_per_block = (rows + gy - 1) / gy;
+  return t;
+}
+constexpr int BN_MAX_BLOCKS = 2048;
+
+// ---- statistics: per-workgroup (count, mean, M2) per channel ----------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, float* __restrict__ part, long long rows, int C,
+                                                         int TX, long long rpb) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
+  const long long rbeg = (long long)blockIdx.y * rpb;
+  long long rend = rbeg + rpb;
+  if (rend > rows) rend = rows;
+  float cnt = 0.f, shift[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { shift[k] = 0.f; s1[k] = 0.f; s2[k] = 0.f; }
+  if (g < GR) {
+    bool first = true;
+    for (long long r = rbeg + ty; r < rend; r += TY) {
+      float v[8];
+      load8(x + r * Cp + g * 8, v);
+      if (first) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) shift[k] = v[k];
+        first = false;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[k] - shift[k]; s1[k] += d; s2[k] += d * d; }
+      cnt += 1.f;
+    }
+  }
+  // per-thread (count, mean, M2), merged over the TY row-lanes through LDS with Chan's formula
+  __shared__ float sh_cnt[256];
+  __shared__ float sh_mean[256][8 + 1];
+  __shared__ float sh_m2[256][8 + 1];
+  sh_cnt[threadIdx.x] = cnt;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float mu = cnt > 0.f ? s1[k] / cnt : 0.f;
+    sh_mean[threadIdx.x][k] = shift[k] + mu;
+    sh_m2[threadIdx.x][k] = cnt > 0.f ? s2[k] - s1[k] * mu : 0.f;
+  }
+  __syncthreads();
+  if (ty == 0 && g < GR) {
+    float n = sh_cnt[tx], mean[8], m2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mean[k] = sh_mean[tx][k]; m2[k] = sh_m2[tx][k]; }
+    for (int j = 1; j < TY; ++j) {
+      const int o = j * TX + tx;
+      const float nb = sh_cnt[o];
+      if (nb > 0.f) {
+        const float nt = n + nb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float d = sh_mean[o][k] - mean[k];
+          mean[k] += d * (nb / nt);
+          m2[k] += sh_m2[o][k] + d * d * (n * nb / nt);
+        }
+        n = nt;
+      }
+    }
+    float* dst = part + (size_t)blockIdx.y * 3 * Cp;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dst[g * 8 + k] = n;
+      dst[Cp + g * 8 + k] = mean[k];
+      dst[2 * Cp + g * 8 + k] = m2[k];
+    }
+  }
+}
+
+__device__ __forceinline__ void bn_write_stats(int c, double n, double mean, double m2, float eps, float momentum, float* mean_o,
+                                               float* rstd_o, float* rmean, float* rvar) {
+  const double var = n > 0 ? m2 / n : 0.0;
+  mean_o[c] = (float)mean;
+  rstd_o[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean != nullptr) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar != nullptr) {
+    const double unb = n > 1 ? m2 / (n - 1) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float eps, float momentum, float* mean_o,
+                                   float* rstd_o, float* rmean, float* rvar) {
+  const int Cp = (C + 7) & ~7;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0, mean = 0, m2 = 0;
+  for (int j = 0; j < nparts; ++j) {
+    const float* src = part + (size_t)j * 3 * Cp;
+    const double nb = src[c];
+    if (nb > 0) {
+      const double nt = n + nb, d = (double)src[Cp + c] - mean;
+      mean += d * (nb / nt);
+      m2 += (double)src[2 * Cp + c] + d * d * (n * nb / nt);
+      n = nt;
+    }
+  }
+  bn_write_stats(c, n, mean, m2, eps, momentum, mean_o, rstd_o, rmean, rvar);
+}
+
+__global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long rows, int C, float eps, float momentum,
+                                    float* mean_o, float* rstd_o, float* rmean, float* rvar) {
+  const int Cp = (C + 7) & ~7;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)rows, s1 = sums[c], s2 = sums[Cp + c];
+  const double mean = s1 / n;
+  double m2 = s2 - s1 * mean;
+  if (m2 < 0) m2 = 0;
+  bn_write_stats(c, n, mean, m2, eps, momentum, mean_o, rstd_o, rmean, rvar);
+}
+
+// ---- forward apply --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int TX,
+                                                         long long rpb, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int act, float slope) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
+  if (g >= GR) return;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g * 8 + k;
+    if (c < C) {
+      sc[k] = rstd[c] * (gamma ? gamma[c] : 1.f);
+      sf[k] = (beta ? beta[c] : 0.f) - mean[c] * sc[k];
+    } else { sc[k] = 0.f; sf[k] = 0.f; }
+  }
+  const long long rbeg = (long long)blockIdx.y * rpb;
+  long long rend = rbeg + rpb;
+  if (rend > rows) rend = rows;
+  for (long long r = rbeg + ty; r < rend; r += TY) {
+    float v[8];
+    load8(x + r * Cp + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < C) ? act_apply(v[k] * sc[k] + sf[k], act, slope) : 0.f;
+    store8(y + r * Cp + g * 8, v);
+  }
+}
+
+// ---- backward reduce: partial sums of g = dy*act'(z) and g*xhat per channel ---------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                 float* __restrict__ part, long long rows, int C, int TX,
+                                                                 long long rpb, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int act, float slope) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
+  float sg[8], sgx[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sg[k] = 0.f; sgx[k] = 0.f; }
+  if (g < GR) {
+    float mu[8], rs[8], ga[8], be[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      const bool ok = c < C;
+      mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
+      ga[k] = ok ? (gamma ? gamma[c] : 1.f) : 0.f; be[k] = ok ? (beta ? beta[c] : 0.f) : 0.f;
+    }
+    const long long rbeg = (long long)blockIdx.y * rpb;
+    long long rend = rbeg + rpb;
+    if (rend > rows) rend = rows;
+    for (long long r = rbeg + ty; r < rend; r += TY) {
+      float v[8], d[8];
+      load8(x + r * Cp + g * 8, v);
+      load8(dy + r * Cp + g * 8, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v[k] - mu[k]) * rs[k];
+        const float gz = d[k] * act_grad_from_in(xh * ga[k] + be[k], act, slope);
+        sg[k] += gz; sgx[k] += gz * xh;
+      }
+    }
+  }
+  __shared__ float sh[256][16 + 1];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sh[threadIdx.x][k] = sg[k]; sh[threadIdx.x][8 + k] = sgx[k]; }
+  __syncthreads();
+  if (ty == 0 && g < GR) {
+    float a[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] = sh[tx][k];
+    for (int j = 1; j < TY; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a[k] += sh[j * TX + tx][k];
+    float* dst = part + (size_t)blockIdx.y * 2 * Cp;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dst[g * 8 + k] = a[k]; dst[Cp + g * 8 + k] = a[8 + k]; }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* dgamma, float* dbeta) {
+  const int Cp = (C + 7) & ~7;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0, sgx = 0;
+  for (int j = 0; j < nparts; ++j) {
+    sg += part[(size_t)j * 2 * Cp + c];
+    sgx += part[(size_t)j * 2 * Cp + Cp + c];
+  }
+  dbeta[c] = (float)sg;
+  dgamma[c] = (float)sgx;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                               long long rows, int C, int TX, long long rpb,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int act, float slope, const float* __restrict__ dgamma,
+                                                               const float* __restrict__ dbeta) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
+  if (g >= GR) return;
+  float mu[8], rs[8], ga[8], be[8], c1[8], c2[8];
+  const float inv = 1.f / (float)rows;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g * 8 + k;
+    const bool ok = c < C;
+    mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
+    ga[k] = ok ? (gamma ? gamma[c] : 1.f) : 0.f; be[k] = ok ? (beta ? beta[c] : 0.f) : 0.f;
+    c1[k] = ok ? dbeta[c] * inv : 0.f; c2[k] = ok ? dgamma[c] * inv : 0.f;
+  }
+  const long long rbeg = (long long)blockIdx.y * rpb;
+  long long rend = rbeg + rpb;
+  if (rend > rows) rend = rows;
+  for (long long r = rbeg + ty; r < rend; r += TY) {
+    float v[8], d[8];
+    load8(x + r * Cp + g * 8, v);
+    load8(dy + r * Cp + g * 8, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (v[k] - mu[k]) * rs[k];
+      const float gz = d[k] * act_grad_from_in(xh * ga[k] + be[k], act, slope);
+      d[k] = ga[k] * rs[k] * (gz - c1[k] - xh * c2[k]);
+    }
+    store8(dx + r * Cp + g * 8, d);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vfd_bn_workspace(int64_t rows, int C) {
+  (void)rows;
+  return (size_t)BN_MAX_BLOCKS * 3 * cpad(C) * sizeof(float);
+}
+
+extern "C" int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
+                            float* running_mean, float* running_var, void* ws, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_stats: bad dtype");
+  VFD_REQUIRE(x && mean && rstd && ws && rows > 0 && C > 0, "bn_stats: bad arguments");
+  const Tiling t = make_tiling(rows, C, BN_MAX_BLOCKS);
+  dim3 grid(t.gx, t.gy);
+  float* part = reinterpret_cast<float*>(ws);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bn_partial_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, part, (long long)rows, C, t.TX, t.rows_per_block);
+  else
+    hipLaunchKernelGGL(bn_partial_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, part, (long long)rows, C, t.TX, t.rows_per_block);
+  VFD_CHECK_LAUNCH("bn_partial");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), part, t.gy, C, eps, momentum, mean,
+                     rstd, running_mean, running_var);
+  VFD_CHECK_LAUNCH("bn_finalize");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
+                                      float* running_mean, float* running_var, void* stream) {
+  VFD_REQUIRE(stats && mean && rstd && rows > 0 && C > 0, "bn_stats_from_sums: bad arguments");
+  hipLaunchKernelGGL(bn_from_sums_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, (long long)rows, C, eps,
+                     momentum, mean, rstd, running_mean, running_var);
+  VFD_CHECK_LAUNCH("bn_from_sums");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, int act, float slope, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_forward: bad dtype");
+  VFD_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_act_forward: bad arguments");
+  const Tiling t = make_tiling(rows, C, 8192);
+  dim3 grid(t.gx, t.gy);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+  VFD_CHECK_LAUNCH("bn_act_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int act, float slope, float* dgamma,
+                                   float* dbeta, void* ws, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_backward: bad dtype");
+  VFD_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && ws && rows > 0 && C > 0, "bn_act_backward: bad arguments");
+  const Tiling t = make_tiling(rows, C, BN_MAX_BLOCKS);
+  dim3 grid(t.gx, t.gy);
+  float* part = reinterpret_cast<float*>(ws);
+  hipStream_t st = as_stream(stream);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bn_act_bwd_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+  VFD_CHECK_LAUNCH("bn_act_bwd_partial");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, t.gy, C, dgamma, dbeta);
+  VFD_CHECK_LAUNCH("bn_bwd_finalize");
+  const Tiling ta = make_tiling(rows, C, 8192);
+  dim3 grid2(ta.gx, ta.gy);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, grid2, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, act, slope, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, grid2, dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, act, slope, dgamma, dbeta);
+  VFD_CHECK_LAUNCH("bn_act_bwd_apply");
+  return VFD_OK;
+}

@@ -1,0 +1,125 @@
+// Shared device/host helpers for libvfdgan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/vfdgan_hip.h"
+
+typedef uint16_t bf16_t;  // bfloat16 bit pattern
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void vfd_set_error(const char* fmt, ...);
+#define VFD_REQUIRE(cond, ...)       \
+  do {                               \
+    if (!(cond)) {                   \
+      vfd_set_error(__VA_ARGS__);    \
+      return VFD_EINVAL;             \
+    }                                \
+  } while (0)
+#define VFD_CHECK_LAUNCH(name)                                        \
+  do {                                                                \
+    hipError_t e__ = hipGetLastError();                               \
+    if (e__ != hipSuccess) {                                          \
+      vfd_set_error("%s: %s", name, hipGetErrorString(e__));          \
+      return VFD_ELAUNCH;                                             \
+    }                                                                 \
+  } while (0)
+
+static inline int cpad(int c) { return (c + 7) & ~7; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16 bytes
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive channels (one CPAD granule) <-> 8 floats
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  uint4 a;
+  a.x = pack2bf(v[0], v[1]); a.y = pack2bf(v[2], v[3]); a.z = pack2bf(v[4], v[5]); a.w = pack2bf(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+
+// ---- activations -----------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float x, int act, float slope) {
+  switch (act) {
+    case VFD_ACT_LRELU: return x > 0.f ? x : x * slope;
+    case VFD_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    case VFD_ACT_TANH: return tanhf(x);
+    default: return x;
+  }
+}
+// derivative expressed from the OUTPUT y = act(x)
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+  switch (act) {
+    case VFD_ACT_LRELU: return y > 0.f ? 1.f : slope;  // slope > 0 keeps the sign; slope == 0: y==0 -> 0
+    case VFD_ACT_SIGMOID: return y * (1.f - y);
+    case VFD_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+// derivative expressed from the INPUT x (pre-activation)
+__device__ __forceinline__ float act_grad_from_in(float x, int act, float slope) {
+  switch (act) {
+    case VFD_ACT_LRELU: return x > 0.f ? 1.f : slope;
+    case VFD_ACT_SIGMOID: { const float y = 1.f / (1.f + __expf(-x)); return y * (1.f - y); }
+    case VFD_ACT_TANH: { const float y = tanhf(x); return 1.f - y * y; }
+    default: return 1.f;
+  }
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -1,0 +1,440 @@
+// HBM-bound plumbing kernels: boundary layout conversion, filter packing, activations, channel concat /
+// split / broadcast, dropout, bias gradient, Adam.  All are 16-byte-per-lane streaming kernels over the
+// channels-last blocks [rows][Cp]; "granule" = 8 consecutive channels of one row.
+#include "common.hpp"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+static inline unsigned ew_blocks(long long n_items) {
+  long long b = (n_items + EW_THREADS - 1) / EW_THREADS;
+  const long long cap = 256LL * 16;  // 256 CUs x 16 resident workgroups, grid-stride beyond
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---- boundary layout ---------------------------------------------------------------------------------
+// src f32 [N][C][S] -> dst T [N][S][Cp].  One thread per (n, s, granule); reads are coalesced along s for
+// each of the 8 channels (a wave reads 8 runs of 64 consecutive floats), writes are 16 B per lane.
+template <typename T>
+__global__ void ncs_to_nsc_kernel(const float* __restrict__ src, T* __restrict__ dst, long long N, int C, long long S) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = N * S * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % S;
+    const long long ng = i / S;
+    const int g = (int)(ng % GR);
+    const long long n = ng / GR;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      v[k] = (c < C) ? src[(n * C + c) * S + s] : 0.f;
+    }
+    store8(dst + (n * S + s) * Cp + g * 8, v);
+  }
+}
+template <typename T>
+__global__ void nsc_to_ncs_kernel(const T* __restrict__ src, float* __restrict__ dst, long long N, int C, long long S) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = N * S * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % S;
+    const long long ng = i / S;
+    const int g = (int)(ng % GR);
+    const long long n = ng / GR;
+    float v[8];
+    load8(src + (n * S + s) * Cp + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      if (c < C) dst[(n * C + c) * S + s] = v[k];
+    }
+  }
+}
+
+// ---- filter packing -----------------------------------------------------------------------------------
+// w f32 [A][B][T] -> packed T [R][T][Ccp] ; transpose_ab=0: R=A,Cc=B ; 1: R=B,Cc=A.  One thread per element
+// of the packed block (pad channels written as zero).
+template <typename T>
+__global__ void pack_filter_kernel(const float* __restrict__ w, T* __restrict__ out, int A, int B, int Tn, int tr) {
+  const int R = tr ? B : A, Cc = tr ? A : B, Ccp = (Cc + 7) & ~7;
+  const long long total = (long long)R * Tn * Ccp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Ccp);
+    const long long rt = i / Ccp;
+    const int t = (int)(rt % Tn);
+    const int r = (int)(rt / Tn);
+    float v = 0.f;
+    if (c < Cc) {
+      const int a = tr ? c : r, b = tr ? r : c;
+      v = w[((long long)a * B + b) * Tn + t];
+    }
+    Elem<T>::st(out + i, v);
+  }
+}
+
+// ---- activation ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int act, float slope) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = rows * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < C) ? act_apply(v[k], act, slope) : 0.f;
+    store8(y + i * 8, v);
+  }
+}
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, long long rows, int C,
+                               int act, float slope) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = rows * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    float v[8], d[8];
+    load8(y + i * 8, v);
+    load8(dy + i * 8, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = (g * 8 + k < C) ? d[k] * act_grad_from_out(v[k], act, slope) : 0.f;
+    store8(dx + i * 8, d);
+  }
+}
+
+// ---- channel plumbing -----------------------------------------------------------------------------------
+template <typename T>
+__global__ void concat_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ dst, long long rows, int Ca,
+                              int Cb) {
+  const int Cap = (Ca + 7) & ~7, Cbp = (Cb + 7) & ~7, Cd = Ca + Cb, Cdp = (Cd + 7) & ~7, GR = Cdp >> 3;
+  const long long total = rows * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    const long long r = i / GR;
+    float v[8];
+    if ((Ca & 7) == 0) {  // granule-aligned: whole-granule copies
+      if (g * 8 < Ca) load8(a + r * Cap + g * 8, v);
+      else load8(b + r * Cbp + (g * 8 - Ca), v);  // b's own pad granule lanes are zero
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = g * 8 + k;
+        v[k] = (c < Ca) ? Elem<T>::ld(a + r * Cap + c) : (c < Cd ? Elem<T>::ld(b + r * Cbp + (c - Ca)) : 0.f);
+      }
+    }
+    store8(dst + r * Cdp + g * 8, v);
+  }
+}
+template <typename T>
+__global__ void split_kernel(const T* __restrict__ src, T* __restrict__ a, T* __restrict__ b, long long rows, int Ca, int Cb) {
+  const int Cap = (Ca + 7) & ~7, Cbp = (Cb + 7) & ~7, Cd = Ca + Cb, Cdp = (Cd + 7) & ~7;
+  const int GA = Cap >> 3, GB = Cbp >> 3, GR = GA + GB;
+  const long long total = rows * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    const long long r = i / GR;
+    float v[8];
+    const bool isa = g < GA;
+    const int gl = isa ? g : g - GA;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cl = gl * 8 + k;
+      const int c = isa ? cl : Ca + cl;
+      const bool ok = isa ? (cl < Ca) : (cl < Cb);
+      v[k] = ok ? Elem<T>::ld(src + r * Cdp + c) : 0.f;
+    }
+    if (isa) store8(a + r * Cap + gl * 8, v);
+    else store8(b + r * Cbp + gl * 8, v);
+  }
+}
+template <typename T>
+__global__ void broadcast_kernel(const T* __restrict__ src, T* __restrict__ dst, long long rows, int reps) {
+  const int Cdp = (reps + 7) & ~7, GR = Cdp >> 3;
+  const long long total = rows * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    const long long r = i / GR;
+    const float s = Elem<T>::ld(src + r * 8);
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < reps) ? s : 0.f;
+    store8(dst + i * 8, v);
+  }
+}
+
+// ---- dropout ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+template <typename T>
+__global__ void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ mout,
+                                   const uint8_t* __restrict__ min, long long n8, float p, uint64_t seed) {
+  const float scale = 1.f / (1.f - p);
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(x + i * 8, v);
+    uint8_t m[8];
+    if (min != nullptr) {
+      const uint2 mm = *reinterpret_cast<const uint2*>(min + i * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = (uint8_t)(((k < 4 ? mm.x : mm.y) >> (8 * (k & 3))) & 0xff);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] = mix_hash(seed, (uint64_t)i * 8 + k) >= thr ? 1 : 0;
+    }
+    uint2 mo = make_uint2(0, 0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = m[k] ? v[k] * scale : 0.f;
+      if (k < 4) mo.x |= (uint32_t)m[k] << (8 * k); else mo.y |= (uint32_t)m[k] << (8 * (k - 4));
+    }
+    store8(y + i * 8, v);
+    if (mout != nullptr) *reinterpret_cast<uint2*>(mout + i * 8) = mo;
+  }
+}
+template <typename T>
+__global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, const uint8_t* __restrict__ mask, long long n8,
+                                   float p) {
+  const float scale = 1.f / (1.f - p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(dy + i * 8, v);
+    const uint2 mm = *reinterpret_cast<const uint2*>(mask + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t m = ((k < 4 ? mm.x : mm.y) >> (8 * (k & 3))) & 0xff;
+      v[k] = m ? v[k] * scale : 0.f;
+    }
+    store8(dx + i * 8, v);
+  }
+}
+
+// ---- bias gradient: db[c] = beta*db[c] + sum_rows dy[row][c] --------------------------------------------------
+// grid.x = granule, one workgroup per granule; threads stride over rows, LDS tree at the end (deterministic).
+template <typename T>
+__global__ void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, long long rows, int C, float beta) {
+  const int Cp = (C + 7) & ~7;
+  const int g = blockIdx.x;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long long r = threadIdx.x; r < rows; r += blockDim.x) {
+    float v[8];
+    load8(dy + r * Cp + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += v[k];
+  }
+  __shared__ float red[8][EW_THREADS / 64];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int c = g * 8 + threadIdx.x;
+    float t = 0.f;
+    for (int w = 0; w < EW_THREADS / 64; ++w) t += red[threadIdx.x][w];
+    if (c < C) db[c] = (beta != 0.f) ? beta * db[c] + t : t;
+  }
+}
+
+// ---- Adam -----------------------------------------------------------------------------------------------------
+// torch.optim.Adam semantics (no amsgrad, no weight decay):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = G[k] * gscale;
+      M[k] = b1 * M[k] + (1.f - b1) * gk;
+      V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+      const float denom = sqrtf(V[k]) / bc2_sqrt + eps;
+      P[k] -= (lr / bc1) * (M[k] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  const long long t0 = n4 << 2;
+  const long long i = t0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float gk = g[i] * gscale;
+    const float mk = b1 * m[i] + (1.f - b1) * gk;
+    const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk; v[i] = vk;
+    p[i] -= (lr / bc1) * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, KERNEL, grid, st, ...)                                                 \
+  do {                                                                                               \
+    if ((dtype) == VFD_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, grid, dim3(EW_THREADS), 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, grid, dim3(EW_THREADS), 0, st, __VA_ARGS__);              \
+  } while (0)
+#define CHECK_DTYPE(dtype, name) VFD_REQUIRE((dtype) == VFD_F32 || (dtype) == VFD_BF16, name ": bad dtype %d", (int)(dtype))
+
+extern "C" int vfd_ncs_to_nsc(int dtype, const float* src, void* dst, int64_t N, int C, int64_t S, void* stream) {
+  CHECK_DTYPE(dtype, "ncs_to_nsc");
+  VFD_REQUIRE(src && dst && N > 0 && C > 0 && S > 0, "ncs_to_nsc: bad arguments");
+  const long long total = (long long)N * S * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(ncs_to_nsc_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), src, (bf16_t*)dst, (long long)N, C, (long long)S);
+  else
+    hipLaunchKernelGGL(ncs_to_nsc_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), src, (float*)dst, (long long)N, C, (long long)S);
+  VFD_CHECK_LAUNCH("ncs_to_nsc");
+  return VFD_OK;
+}
+
+extern "C" int vfd_nsc_to_ncs(int dtype, const void* src, float* dst, int64_t N, int C, int64_t S, void* stream) {
+  CHECK_DTYPE(dtype, "nsc_to_ncs");
+  VFD_REQUIRE(src && dst && N > 0 && C > 0 && S > 0, "nsc_to_ncs: bad arguments");
+  const long long total = (long long)N * S * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(nsc_to_ncs_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)src, dst, (long long)N, C, (long long)S);
+  else
+    hipLaunchKernelGGL(nsc_to_ncs_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, dst, (long long)N, C, (long long)S);
+  VFD_CHECK_LAUNCH("nsc_to_ncs");
+  return VFD_OK;
+}
+
+extern "C" int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T, int transpose_ab, void* stream) {
+  CHECK_DTYPE(dtype, "pack_filter");
+  VFD_REQUIRE(w && packed && A > 0 && B > 0 && T > 0, "pack_filter: bad arguments");
+  const int R = transpose_ab ? B : A, Cc = transpose_ab ? A : B;
+  const long long total = (long long)R * T * cpad(Cc);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), w, (bf16_t*)packed, A, B, T, transpose_ab);
+  else
+    hipLaunchKernelGGL(pack_filter_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), w, (float*)packed, A, B, T, transpose_ab);
+  VFD_CHECK_LAUNCH("pack_filter");
+  return VFD_OK;
+}
+
+extern "C" int vfd_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, int act, float slope, void* stream) {
+  CHECK_DTYPE(dtype, "act_forward");
+  VFD_REQUIRE(x && y && rows > 0 && C > 0, "act_forward: bad arguments");
+  const long long total = (long long)rows * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(act_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, (long long)rows, C, act, slope);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, (long long)rows, C, act, slope);
+  VFD_CHECK_LAUNCH("act_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_act_backward(int dtype, const void* y, const void* dy, void* dx, int64_t rows, int C, int act, float slope,
+                                void* stream) {
+  CHECK_DTYPE(dtype, "act_backward");
+  VFD_REQUIRE(y && dy && dx && rows > 0 && C > 0, "act_backward: bad arguments");
+  const long long total = (long long)rows * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, (long long)rows, C, act, slope);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)y, (const float*)dy, (float*)dx, (long long)rows, C, act, slope);
+  VFD_CHECK_LAUNCH("act_backward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_concat_channels(int dtype, const void* a, const void* b, void* dst, int64_t rows, int Ca, int Cb, void* stream) {
+  CHECK_DTYPE(dtype, "concat");
+  VFD_REQUIRE(a && b && dst && rows > 0 && Ca > 0 && Cb > 0, "concat: bad arguments");
+  const long long total = (long long)rows * (cpad(Ca + Cb) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(concat_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)dst, (long long)rows, Ca, Cb);
+  else
+    hipLaunchKernelGGL(concat_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)a, (const float*)b, (float*)dst, (long long)rows, Ca, Cb);
+  VFD_CHECK_LAUNCH("concat");
+  return VFD_OK;
+}
+
+extern "C" int vfd_split_channels(int dtype, const void* src, void* a, void* b, int64_t rows, int Ca, int Cb, void* stream) {
+  CHECK_DTYPE(dtype, "split");
+  VFD_REQUIRE(src && a && b && rows > 0 && Ca > 0 && Cb > 0, "split: bad arguments");
+  const long long total = (long long)rows * ((cpad(Ca) + cpad(Cb)) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(split_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)src, (bf16_t*)a, (bf16_t*)b, (long long)rows, Ca, Cb);
+  else
+    hipLaunchKernelGGL(split_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, (float*)a, (float*)b, (long long)rows, Ca, Cb);
+  VFD_CHECK_LAUNCH("split");
+  return VFD_OK;
+}
+
+extern "C" int vfd_broadcast_channel(int dtype, const void* src, void* dst, int64_t rows, int reps, void* stream) {
+  CHECK_DTYPE(dtype, "broadcast");
+  VFD_REQUIRE(src && dst && rows > 0 && reps > 0, "broadcast: bad arguments");
+  const long long total = (long long)rows * (cpad(reps) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(broadcast_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)src, (bf16_t*)dst, (long long)rows, reps);
+  else
+    hipLaunchKernelGGL(broadcast_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, (float*)dst, (long long)rows, reps);
+  VFD_CHECK_LAUNCH("broadcast");
+  return VFD_OK;
+}
+
+extern "C" int vfd_dropout_forward(int dtype, const void* x, void* y, uint8_t* mask_out, const uint8_t* mask_in, int64_t n,
+                                   float p, uint64_t seed, void* stream) {
+  CHECK_DTYPE(dtype, "dropout_forward");
+  VFD_REQUIRE(x && y && n > 0 && (n & 7) == 0, "dropout_forward: n must be a positive multiple of 8");
+  VFD_REQUIRE(p >= 0.f && p < 1.f, "dropout_forward: p must be in [0,1)");
+  const long long n8 = n >> 3;
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, mask_out, mask_in, n8, p, seed);
+  else
+    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, mask_out, mask_in, n8, p, seed);
+  VFD_CHECK_LAUNCH("dropout_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_dropout_backward(int dtype, const void* dy, void* dx, const uint8_t* mask, int64_t n, float p, void* stream) {
+  CHECK_DTYPE(dtype, "dropout_backward");
+  VFD_REQUIRE(dy && dx && mask && n > 0 && (n & 7) == 0, "dropout_backward: bad arguments");
+  const long long n8 = n >> 3;
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, mask, n8, p);
+  else
+    hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, mask, n8, p);
+  VFD_CHECK_LAUNCH("dropout_backward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* stream) {
+  CHECK_DTYPE(dtype, "bias_grad");
+  VFD_REQUIRE(dy && db && rows > 0 && C > 0, "bias_grad: bad arguments");
+  const unsigned grid = (unsigned)(cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)dy, db, (long long)rows, C, beta);
+  else
+    hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, as_stream(stream), (const float*)dy, db, (long long)rows, C, beta);
+  VFD_CHECK_LAUNCH("bias_grad");
+  return VFD_OK;
+}
+
+extern "C" int vfd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int32_t step, float grad_scale, void* stream) {
+  VFD_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam: bad arguments");
+  VFD_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+              "adam: arenas must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(EW_THREADS), 0, as_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, (long long)n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  VFD_CHECK_LAUNCH("adam");
+  return VFD_OK;
+}

@@ -1,0 +1,134 @@
+"""Data parallelism for the GAN step: one process per GPU, gradients summed with RCCL over xGMI.
+
+Replaces the reference's single-process ``torch.nn.DataParallel`` (models/mygannet.py:232-237,
+models/anogan.py:126-131).  Numerical contract: mean-loss gradient over the GLOBAL batch,
+BatchNorm statistics per replica (unsynchronised), replicas start from identical weights (broadcast from rank 0).
+
+The reducer works on the flat gradient arena of :class:`vfd_gan_amd.optim.Adam`: parameters are grouped into a
+few large contiguous buckets (xGMI is point-to-point, ~153 GB/s per link: few large collectives beat many small
+ones); a bucket's all-reduce is launched from autograd's post-accumulate hooks as soon as its last gradient has
+landed, so it overlaps the rest of the backward pass; ``finish()`` joins before the optimiser step.  The 1/world
+factor is folded into the Adam kernel (``optimizer.grad_scale``), not applied as a separate pass.
+"""
+import os
+
+import torch
+import torch.distributed as tdist
+
+
+def is_initialized():
+    return tdist.is_available() and tdist.is_initialized()
+
+
+def rank():
+    return tdist.get_rank() if is_initialized() else 0
+
+
+def world_size():
+    return tdist.get_world_size() if is_initialized() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); no-op for a single process.
+    backend defaults to "nccl" (= RCCL on ROCm) when a GPU is present, else "gloo"."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or is_initialized():
+        return rank(), world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    use_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if use_gpu:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+    tdist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    return rank(), world_size()
+
+
+def broadcast_module(module, src=0):
+    """Make every replica start from rank `src`'s parameters and buffers (DataParallel replicates each forward)."""
+    if world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            tdist.broadcast(t.data, src=src)
+
+
+def make_buckets(slices, bucket_elems):
+    """Group consecutive (offset, numel) parameter slices — walked in REVERSE registration order, which is roughly
+    the order gradients become ready — into contiguous [lo, hi) ranges of about `bucket_elems` elements.
+    Returns (buckets, owner) with buckets = [(lo, hi, [param indices])], owner[i] = bucket of parameter i."""
+    buckets, owner = [], [None] * len(slices)
+    cur, lo, hi = [], None, None
+    for i in range(len(slices) - 1, -1, -1):
+        o, n = slices[i]
+        if lo is None:
+            lo, hi = o, o + n
+        lo, hi = min(lo, o), max(hi, o + n)
+        cur.append(i)
+        if hi - lo >= bucket_elems:
+            buckets.append((lo, hi, cur))
+            cur, lo, hi = [], None, None
+    if cur:
+        buckets.append((lo, hi, cur))
+    for b, (_, _, idxs) in enumerate(buckets):
+        for i in idxs:
+            owner[i] = b
+    return buckets, owner
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped gradient all-reduce over a flat gradient arena."""
+
+    def __init__(self, params, grad_arena, slices, bucket_mb=32.0):
+        self.params = list(params)
+        self.arena = grad_arena
+        self.world = world_size()
+        self.buckets, self.owner = make_buckets(slices, int(bucket_mb * (1 << 20) / 4))
+        self.pending = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+        self.enabled = True
+        self._hooks = []
+        for i, p in enumerate(self.params):
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        self.reset()
+
+    @classmethod
+    def for_optimizer(cls, opt, bucket_mb=32.0):
+        r = cls(opt._params, opt.grad_arena, opt.slices(), bucket_mb)
+        opt.grad_scale = 1.0 / r.world
+        return r
+
+    def reset(self):
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            self.pending[b] = sum(1 for i in idxs if self.params[i].requires_grad)
+            self.launched[b] = False
+        self.handles = []
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        if self.world > 1:
+            lo, hi, _ = self.buckets[b]
+            self.handles.append(tdist.all_reduce(self.arena[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if not self.enabled:
+                return
+            b = self.owner[i]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def finish(self):
+        """Launch whatever has not been launched (parameters that received no gradient), wait for all buckets
+        (the current stream waits; the host does not block with RCCL), and re-arm for the next backward."""
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.reset()

@@ -1,0 +1,597 @@
+"""Autograd glue over the C ABI (include/vfdgan_hip.h).
+
+Every op here is a `torch.autograd.Function` whose forward and backward launch hand-written HIP kernels from
+libvfdgan_hip.so on torch's current stream.  Tensors that flow between ops are channels-last blocks
+``t[N, D, H, W, Cp]`` (Cp = C rounded up to 8, pad channels zero) in the compute dtype (bfloat16 or float32),
+wrapped in :class:`ClTensor`, which remembers the logical channel count.  PyTorch supplies device memory,
+streams and the autograd tape; no arithmetic of the hot path is done by torch operators.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, dtype_code, load, ptr, stream
+
+_COMPUTE_DTYPE = torch.bfloat16
+
+
+def set_compute_dtype(dt):
+    """Storage type of activations / packed filters: torch.bfloat16 (default, MFMA bf16) or torch.float32."""
+    global _COMPUTE_DTYPE
+    if isinstance(dt, str):
+        dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
+              "float32": torch.float32}[dt]
+    dtype_code(dt)
+    _COMPUTE_DTYPE = dt
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
+
+
+def cpad(c):
+    return (c + 7) & ~7
+
+
+class ClTensor:
+    """A channels-last activation block plus its logical channel count.
+
+    ``t``   torch tensor [N, D, H, W, Cp] (part of the autograd graph)
+    ``C``   logical channels (pad channels t[..., C:] are zero)
+    ``nsp`` spatial rank seen by the user: 3 -> (N,C,D,H,W), 2 -> (N,C,H,W), 0 -> (N,C)
+    """
+    __slots__ = ("t", "C", "nsp")
+
+    def __init__(self, t, C, nsp):
+        self.t, self.C, self.nsp = t, C, nsp
+
+    @property
+    def shape(self):
+        n, d, h, w, _ = self.t.shape
+        return {3: (n, self.C, d, h, w), 2: (n, self.C, h, w), 0: (n, self.C)}[self.nsp]
+
+    @property
+    def rows(self):
+        n, d, h, w, _ = self.t.shape
+        return n * d * h * w
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    def detach(self):
+        return ClTensor(self.t.detach(), self.C, self.nsp)
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def to_torch(self):
+        """float32 tensor in the reference's layout (N,C,[D,]H,W)."""
+        return from_cl(self)
+
+    def __repr__(self):
+        return "ClTensor(shape=%s, dtype=%s)" % (self.shape, self.t.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# boundary layout conversion
+# ---------------------------------------------------------------------------------------------------------
+class _ToCl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        _lib.require_device(x)
+        x = x.contiguous().float()
+        N, C = x.shape[0], x.shape[1]
+        sp = tuple(x.shape[2:])
+        S = 1
+        for s in sp:
+            S *= s
+        dhw = {3: sp, 2: (1,) + sp, 0: (1, 1, 1)}[len(sp)]
+        out = torch.empty((N,) + dhw + (cpad(C),), dtype=dt, device=x.device)
+        check(load().vfd_ncs_to_nsc(dtype_code(dt), x.data_ptr(), out.data_ptr(), N, C, S, stream()), "ncs_to_nsc")
+        ctx.meta = (N, C, S, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, S, shape = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        check(load().vfd_nsc_to_ncs(dtype_code(g.dtype), g.data_ptr(), out.data_ptr(), N, C, S, stream()), "nsc_to_ncs")
+        return out, None
+
+
+class _FromCl(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, C, nsp):
+        t = t.contiguous()
+        N, D, H, W, Cp = t.shape
+        S = D * H * W
+        shape = {3: (N, C, D, H, W), 2: (N, C, H, W), 0: (N, C)}[nsp]
+        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+        check(load().vfd_nsc_to_ncs(dtype_code(t.dtype), t.data_ptr(), out.data_ptr(), N, C, S, stream()), "nsc_to_ncs")
+        ctx.meta = (N, C, S, tuple(t.shape), t.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, S, shape, dt = ctx.meta
+        g = g.contiguous().float()
+        out = torch.empty(shape, dtype=dt, device=g.device)
+        check(load().vfd_ncs_to_nsc(dtype_code(dt), g.data_ptr(), out.data_ptr(), N, C, S, stream()), "ncs_to_nsc")
+        return out, None, None
+
+
+def to_cl(x, dtype=None):
+    """(N,C,[D,]H,W) or (N,C) float tensor -> ClTensor in the compute dtype."""
+    if isinstance(x, ClTensor):
+        return x
+    nsp = x.dim() - 2
+    if nsp not in (0, 2, 3):
+        raise ValueError("expected (N,C), (N,C,H,W) or (N,C,D,H,W), got %s" % (tuple(x.shape),))
+    return ClTensor(_ToCl.apply(x, dtype or _COMPUTE_DTYPE), x.shape[1], nsp)
+
+
+def from_cl(x):
+    if not isinstance(x, ClTensor):
+        return x
+    return _FromCl.apply(x.t, x.C, x.nsp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution family
+# ---------------------------------------------------------------------------------------------------------
+_WEIGHT_EPOCH = [0]
+
+
+def invalidate_weight_cache():
+    """Packed (bf16, K-major) filter copies are cached per parameter; bump this after mutating parameters
+    behind autograd's back (``param.data.normal_()``, a fused optimiser step)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def _triple(v, nsp, fill=1):
+    """Per-dimension (D,H,W) triple from an int or an nsp-tuple; missing leading dims get `fill`."""
+    if isinstance(v, int):
+        v = (v,) * max(nsp, 1) if nsp > 0 else ()
+    v = tuple(v)
+    return (fill,) * (3 - len(v)) + v if len(v) < 3 else v
+
+
+def _packed_filter(weight, dt, transpose_ab, A, B, T):
+    """Cached K-major copy of a filter parameter (see vfd_pack_filter)."""
+    cache = weight.__dict__.setdefault("_vfd_packed", {})
+    key = (dt, transpose_ab)
+    tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    R, Cc = (B, A) if transpose_ab else (A, B)
+    out = torch.empty((R, T, cpad(Cc)), dtype=dt, device=weight.device)
+    w = weight.detach()
+    if not w.is_contiguous() or w.dtype != torch.float32:
+        w = w.contiguous().float()
+    check(load().vfd_pack_filter(dtype_code(dt), w.data_ptr(), out.data_ptr(), A, B, T, int(transpose_ab), stream()),
+          "pack_filter")
+    cache[key] = (tag, out)
+    return out
+
+
+def _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act=0, slope=0.0):
+    d = ConvDesc()
+    d.N = N
+    d.Di, d.Hi, d.Wi = in_dhw
+    d.Cin = Cin
+    d.Do, d.Ho, d.Wo = out_dhw
+    d.Cout = Cout
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = s
+    d.pd, d.ph, d.pw = p
+    d.transposed = int(transposed)
+    d.dtype = dtype_code(dt)
+    d.act = act
+    d.slope = slope
+    return d
+
+
+def _conv_launch(desc, x, packed, bias, out, stats=None):
+    check(load().vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
+                                  ptr(stats), stream()), "conv_forward")
+
+
+class _Conv(torch.autograd.Function):
+    """y = act(conv(x, w) + b) for regular and transposed convolutions (fwd: implicit GEMM; bwd: gather-form data
+    gradient through the same kernel with swapped roles + split-K filter gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, stats):
+        (Cin, Cout, k, s, p, out_dhw, transposed, act, slope) = geom
+        x = x.contiguous()
+        N = x.shape[0]
+        in_dhw = tuple(x.shape[1:4])
+        dt = x.dtype
+        T = k[0] * k[1] * k[2]
+        A, B = (Cin, Cout) if transposed else (Cout, Cin)  # torch filter layout [A][B][T]
+        packed = _packed_filter(weight, dt, transpose_ab=bool(transposed), A=A, B=B, T=T)
+        out = torch.empty((N,) + tuple(out_dhw) + (cpad(Cout),), dtype=dt, device=x.device)
+        desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act, slope)
+        b = bias.detach() if bias is not None else None
+        _conv_launch(desc, x, packed, b, out, stats)
+        ctx.geom = geom
+        ctx.in_dhw = in_dhw
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        (Cin, Cout, k, s, p, out_dhw, transposed, act, slope) = ctx.geom
+        x, weight, y = ctx.saved_tensors
+        lib = load()
+        gy = gy.contiguous()
+        dt = x.dtype
+        N = x.shape[0]
+        in_dhw = ctx.in_dhw
+        T = k[0] * k[1] * k[2]
+        rows_out = N * out_dhw[0] * out_dhw[1] * out_dhw[2]
+        if act != _lib.ACT_NONE:  # g = dy * act'(y), from the saved output
+            g = torch.empty_like(gy)
+            check(lib.vfd_act_backward(dtype_code(dt), y.data_ptr(), gy.data_ptr(), g.data_ptr(), rows_out, Cout, act,
+                                       slope, stream()), "act_backward")
+            gy = g
+        A, B = (Cin, Cout) if transposed else (Cout, Cin)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = the opposite kind of convolution with the A/B-swapped filter packing
+            packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
+            gx = torch.empty_like(x)
+            desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
+            _conv_launch(desc, gy, packed, None, gx)
+        if ctx.needs_input_grad[1]:
+            desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
+            nsplit = ctypes.c_int32()
+            nbytes = ctypes.c_size_t()
+            check(lib.vfd_wgrad_workspace(ctypes.byref(desc), ctypes.byref(nsplit), ctypes.byref(nbytes)), "wgrad_workspace")
+            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+            check(lib.vfd_conv_wgrad(ctypes.byref(desc), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, stream()),
+                  "conv_wgrad")
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+            check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
+            check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, stream()), "bias_grad")
+        return gx, gw, gb, None, None
+
+
+def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, act=_lib.ACT_NONE, slope=0.0,
+         stats=None):
+    """Convolution on a ClTensor.  `weight` is the torch-layout float32 parameter ([Cout,Cin,k..] or, transposed,
+    [Cin,Cout,k..]); Linear layers pass a [out,in] matrix with x.nsp == 0."""
+    nsp = x.nsp
+    if weight.dim() == 2:
+        k = (1, 1, 1)
+        Cout, Cin = weight.shape
+    else:
+        k = _triple(tuple(weight.shape[2:]), nsp, 1)
+        if transposed:
+            Cin, Cout = weight.shape[0], weight.shape[1]
+        else:
+            Cout, Cin = weight.shape[0], weight.shape[1]
+    if Cin != x.C:
+        raise RuntimeError("conv: input has %d channels, filter expects %d" % (x.C, Cin))
+    s = _triple(stride, nsp, 1)
+    p = _triple(padding, nsp, 0)
+    op = _triple(output_padding, nsp, 0)
+    in_dhw = tuple(x.t.shape[1:4])
+    if transposed:
+        out_dhw = tuple((in_dhw[i] - 1) * s[i] - 2 * p[i] + k[i] + op[i] for i in range(3))
+    else:
+        out_dhw = tuple((in_dhw[i] + 2 * p[i] - k[i]) // s[i] + 1 for i in range(3))
+    if min(out_dhw) <= 0:
+        raise RuntimeError("conv: kernel %s does not fit input %s (padding %s)" % (k, in_dhw, p))
+    geom = (Cin, Cout, k, s, p, out_dhw, bool(transposed), act, float(slope))
+    out = _Conv.apply(x.t, weight, bias, geom, stats)
+    return ClTensor(out, Cout, nsp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BatchNorm (train mode) + activation
+# ---------------------------------------------------------------------------------------------------------
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums):
+        lib = load()
+        x = x.contiguous()
+        rows = x.numel() // x.shape[-1]
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        dtc = dtype_code(x.dtype)
+        if sums is not None:
+            check(lib.vfd_bn_stats_from_sums(sums.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
+                                             ptr(running_mean), ptr(running_var), stream()), "bn_stats_from_sums")
+        else:
+            ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
+            check(lib.vfd_bn_stats(dtc, x.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
+                                   ptr(running_mean), ptr(running_var), ws.data_ptr(), stream()), "bn_stats")
+        y = torch.empty_like(x)
+        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+        check(lib.vfd_bn_act_forward(dtc, x.data_ptr(), y.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), ptr(g_),
+                                     ptr(b_), act, slope, stream()), "bn_act_forward")
+        ctx.meta = (rows, C, act, slope)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = load()
+        rows, C, act, slope = ctx.meta
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
+        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+        check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
+                                      mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
+                                      dbeta.data_ptr(), ws.data_ptr(), stream()), "bn_act_backward")
+        return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None, None, None, None, None,
+                None, None, None, None)
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,
+           sums=None):
+    """Training-mode batch normalisation over all rows of `x` followed by `act`; updates the running statistics
+    in place (momentum rule, unbiased variance) exactly like torch.nn.BatchNormNd.train()."""
+    y = _BnAct.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act),
+                     float(slope), sums)
+    return ClTensor(y, x.C, x.nsp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# element-wise activation
+# ---------------------------------------------------------------------------------------------------------
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C, act, slope):
+        x = x.contiguous()
+        rows = x.numel() // x.shape[-1]
+        y = torch.empty_like(x)
+        check(load().vfd_act_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), rows, C, act, slope, stream()),
+              "act_forward")
+        ctx.meta = (rows, C, act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        rows, C, act, slope = ctx.meta
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = torch.empty_like(gy)
+        check(load().vfd_act_backward(dtype_code(y.dtype), y.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C, act, slope,
+                                      stream()), "act_backward")
+        return dx, None, None, None
+
+
+def activation(x, act, slope=0.0):
+    return ClTensor(_Act.apply(x.t, x.C, int(act), float(slope)), x.C, x.nsp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pooling / resampling / channel plumbing / dropout
+# ---------------------------------------------------------------------------------------------------------
+class _AvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C, k):
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        y = torch.empty((N, D // k[0], H // k[1], W // k[2], Cp), dtype=x.dtype, device=x.device)
+        check(load().vfd_avgpool_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), N, D, H, W, C, k[0], k[1], k[2],
+                                         stream()), "avgpool_forward")
+        ctx.meta = (N, D, H, W, C, k, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, D, H, W, C, k, shape = ctx.meta
+        gy = gy.contiguous()
+        dx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        check(load().vfd_avgpool_backward(dtype_code(gy.dtype), gy.data_ptr(), dx.data_ptr(), N, D, H, W, C, k[0], k[1],
+                                          k[2], stream()), "avgpool_backward")
+        return dx, None, None
+
+
+def avg_pool(x, kernel):
+    k = _triple(kernel, x.nsp, 1)
+    return ClTensor(_AvgPool.apply(x.t, x.C, k), x.C, x.nsp)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C):
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, Cp), dtype=x.dtype, device=x.device)
+        check(load().vfd_upsample2x_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), N, D, H, W, C, stream()),
+              "upsample2x_forward")
+        ctx.meta = (N, D, H, W, C, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, D, H, W, C, shape = ctx.meta
+        gy = gy.contiguous()
+        dx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        check(load().vfd_upsample2x_backward(dtype_code(gy.dtype), gy.data_ptr(), dx.data_ptr(), N, D, H, W, C, stream()),
+              "upsample2x_backward")
+        return dx, None
+
+
+def upsample_trilinear2x(x):
+    if x.nsp != 3:
+        raise RuntimeError("upsample_trilinear2x expects an (N,C,D,H,W) block")
+    return ClTensor(_Upsample2x.apply(x.t, x.C), x.C, x.nsp)
+
+
+class _Concat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, Ca, Cb):
+        a, b = a.contiguous(), b.contiguous()
+        rows = a.numel() // a.shape[-1]
+        out = torch.empty(tuple(a.shape[:-1]) + (cpad(Ca + Cb),), dtype=a.dtype, device=a.device)
+        check(load().vfd_concat_channels(dtype_code(a.dtype), a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, Ca, Cb,
+                                         stream()), "concat")
+        ctx.meta = (rows, Ca, Cb, tuple(a.shape), tuple(b.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, Ca, Cb, sa, sb = ctx.meta
+        g = g.contiguous()
+        ga = torch.empty(sa, dtype=g.dtype, device=g.device)
+        gb = torch.empty(sb, dtype=g.dtype, device=g.device)
+        check(load().vfd_split_channels(dtype_code(g.dtype), g.data_ptr(), ga.data_ptr(), gb.data_ptr(), rows, Ca, Cb,
+                                        stream()), "split")
+        return ga, gb, None, None
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) on ClTensors."""
+    if tuple(a.t.shape[:-1]) != tuple(b.t.shape[:-1]):
+        raise RuntimeError("cat: spatial shapes differ: %s vs %s" % (a.shape, b.shape))
+    return ClTensor(_Concat.apply(a.t, b.t, a.C, b.C), a.C + b.C, a.nsp)
+
+
+def gray2rgb(x):
+    """lib/utils.py:91-92 of the reference: cat([v, v, v], dim=1) of a 1-channel block (no gradient needed:
+    the reference only applies it to detached tensors, models/mygannet.py:279-280)."""
+    if x.C != 1:
+        raise RuntimeError("gray2rgb expects 1 channel")
+    src = x.t.detach().contiguous()
+    rows = src.numel() // src.shape[-1]
+    out = torch.empty_like(src)  # CPAD(3) == CPAD(1) == 8
+    check(load().vfd_broadcast_channel(dtype_code(src.dtype), src.data_ptr(), out.data_ptr(), rows, 3, stream()), "broadcast")
+    return ClTensor(out, 3, x.nsp)
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, mask_in):
+        x = x.contiguous()
+        n = x.numel()
+        y = torch.empty_like(x)
+        mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+        check(load().vfd_dropout_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), mask.data_ptr(), ptr(mask_in), n, p,
+                                         seed, stream()), "dropout_forward")
+        ctx.p = p
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (mask,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = torch.empty_like(gy)
+        check(load().vfd_dropout_backward(dtype_code(gy.dtype), gy.data_ptr(), dx.data_ptr(), mask.data_ptr(), gy.numel(),
+                                          ctx.p, stream()), "dropout_backward")
+        return dx, None, None, None
+
+
+_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "mask_provider": None}
+
+
+def dropout_manual_seed(seed):
+    _DROPOUT_STATE["seed"] = int(seed)
+    _DROPOUT_STATE["calls"] = 0
+
+
+def set_dropout_mask_provider(fn):
+    """Parity hook: fn(logical_shape, p, call_index) -> bool/uint8 keep-mask (torch tensor, reference layout
+    (N,C,D,H,W)) or None.  Lets tests impose the masks the CPU oracle used (torch's CPU and device RNG streams
+    differ)."""
+    _DROPOUT_STATE["mask_provider"] = fn
+    _DROPOUT_STATE["calls"] = 0
+
+
+def dropout(x, p, training=True):
+    if not training or p == 0.0:
+        return x
+    st = _DROPOUT_STATE
+    idx = st["calls"]
+    st["calls"] += 1
+    mask_in = None
+    if st["mask_provider"] is not None:
+        m = st["mask_provider"](x.shape, p, idx)
+        if m is not None:
+            # reference layout -> channels-last uint8 with padded channels (pad lanes irrelevant: inputs there are 0)
+            m = m.to(device=x.t.device, dtype=torch.float32)
+            mcl = to_cl(m, dtype=torch.float32).t
+            mask_in = (mcl != 0).to(torch.uint8).contiguous().view(-1)
+    seed = (st["seed"] * 0x9E3779B1 + idx * 0x85EBCA6B) & 0xFFFFFFFFFFFFFFFF
+    return ClTensor(_Dropout.apply(x.t, float(p), seed, mask_in), x.C, x.nsp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------------------------------------
+class _Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, kind, C, bconst, pos_weight):
+        lib = load()
+        a = a.contiguous()
+        if b is not None:
+            b = b.contiguous()
+        rows = a.numel() // a.shape[-1]
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = torch.empty(lib.vfd_loss_workspace(rows, C), dtype=torch.uint8, device=a.device)
+        check(lib.vfd_loss_forward(kind, dtype_code(a.dtype), a.data_ptr(), ptr(b), bconst, loss.data_ptr(), rows, C,
+                                   pos_weight, ws.data_ptr(), stream()), "loss_forward")
+        ctx.meta = (kind, C, rows, bconst, pos_weight)
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        kind, C, rows, bconst, pos_weight = ctx.meta
+        a, b = ctx.saved_tensors
+        gout = gout.contiguous().float()
+        need_a = ctx.needs_input_grad[0]
+        need_b = b is not None and ctx.needs_input_grad[1]
+        ga = torch.empty_like(a) if need_a else None
+        gb = torch.empty_like(b) if need_b else None
+        if need_a or need_b:
+            check(load().vfd_loss_backward(kind, dtype_code(a.dtype), a.data_ptr(), ptr(b), bconst, gout.data_ptr(), ptr(ga),
+                                           ptr(gb), rows, C, 1.0, pos_weight, stream()), "loss_backward")
+        return ga, gb, None, None, None, None
+
+
+def _loss(kind, a, b, pos_weight=2.0):
+    if isinstance(b, ClTensor):
+        if tuple(a.t.shape) != tuple(b.t.shape):
+            raise RuntimeError("loss: shapes differ: %s vs %s" % (a.shape, b.shape))
+        return _Loss.apply(a.t, b.t, kind, a.C, 0.0, float(pos_weight))
+    return _Loss.apply(a.t, None, kind, a.C, float(b), float(pos_weight))
+
+
+def l2_loss(a, b):
+    """lib/utils.py:59-63 (size_average=True): mean((a-b)^2).  `b` is a ClTensor or a Python float."""
+    return _loss(_lib.LOSS_L2, a, b)
+
+
+def l1_loss(a, b):
+    """nn.L1Loss() (models/ganomaly.py:438)."""
+    return _loss(_lib.LOSS_L1, a, b)
+
+
+def bce_loss(a, b):
+    """nn.BCELoss() mean (models/mygannet.py:267); `b` may be a constant label (1.0 / 0.0)."""
+    return _loss(_lib.LOSS_BCE, a, b)
+
+
+def weighted_bce(a, b, pos_weight=2):
+    """lib/utils.py:65-71."""
+    return _loss(_lib.LOSS_WBCE, a, b, pos_weight if pos_weight is not None else 1.0)

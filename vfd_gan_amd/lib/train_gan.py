@@ -1,0 +1,114 @@
+"""Trainer base with the attributes and loop of the reference's lib/train_gan.py:17-85.
+
+Same public surface (``GANBaseModel(args, dataloader)``, ``.train()``, ``.save_weights(name_head)``, the
+``*_dict`` summaries, ``save_root_dir`` / ``weight_dir`` naming, ``args.txt``); subclasses supply
+``optimize_params()`` and optionally ``test()``.  TensorBoard (absent in this image) is replaced by a JSON-lines
+scalar log; the periodic full test sweep is an eval feature outside the hot path and runs
+only when a subclass defines ``test``.
+"""
+import json
+import os
+from collections import OrderedDict
+from datetime import datetime
+
+import torch
+
+from .. import dist as vdist
+
+
+class ScalarLog:
+    """Minimal stand-in for torch.utils.tensorboard.SummaryWriter (scalars only, JSON lines)."""
+
+    def __init__(self, log_dir):
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+
+    def add_scalars(self, main_tag, tag_scalar_dict, global_step=None):
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"step": global_step, "tag": main_tag, **{k: float(v) for k, v in tag_scalar_dict.items()}}) + "\n")
+
+    def add_scalar(self, tag, value, global_step=None):
+        self.add_scalars(tag, {"value": value}, global_step)
+
+
+class GANBaseModel():
+    def __init__(self, args, dataloader):
+        self.args = args
+        self.dataloader = dataloader
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if self.device is None:
+            raise RuntimeError("vfd_gan_amd trainers need a HIP device (no CPU fallback on the product path)")
+
+        self.global_step = 0
+        self.epoch = 0
+        self.best_roc = 0
+        self.best_pr = 0
+        self.color_video_dict = OrderedDict()
+        self.gray_video_dict = OrderedDict()
+        self.errors_dict = {}
+        self.hist_dict = OrderedDict()
+        self.score_dict = OrderedDict()
+
+        self.rank, self.world_size = vdist.rank(), vdist.world_size()
+        current_time = datetime.now().strftime("%b%d_%H-%M-%S")
+        comment = "b{}xd{}xwh{}_lr-{}_w-a{}c{}".format(args.batchsize, args.nfr, args.isize,
+                                                       args.lr, args.w_adv, args.w_con)
+        self.save_root_dir = os.path.join(args.result_root, args.model, comment, current_time)
+        self.weight_dir = os.path.join(self.save_root_dir, 'weights')
+        logdir = os.path.join(self.save_root_dir, "runs")
+        self.writer = None
+        if self.rank == 0:
+            os.makedirs(self.weight_dir, exist_ok=True)
+            os.makedirs(logdir, exist_ok=True)
+            self.writer = ScalarLog(logdir)
+            with open(self.save_root_dir + "/args.txt", mode="w") as f:
+                json.dump(args.__dict__, f, indent=4)
+            print("\n SAVE PATH == {} \n".format(self.save_root_dir))
+
+    def save_weights(self, name_head):
+        """Reference lib/train_gan.py:52-57: ``{name}_ep%04d_netG.pth`` / ``_netD.pth`` holding {'epoch','state_dict'}."""
+        if self.rank != 0:
+            return
+        torch.save({'epoch': self.epoch + 1, 'state_dict': self.netg.state_dict()},
+                   '%s/%s_ep%04d_netG.pth' % (self.weight_dir, name_head, self.epoch))
+        torch.save({'epoch': self.epoch + 1, 'state_dict': self.netd.state_dict()},
+                   '%s/%s_ep%04d_netD.pth' % (self.weight_dir, name_head, self.epoch))
+
+    def set_input(self, data):
+        self.input, self.real, self.gt, self.lb = (d.to(self.device, non_blocking=True) for d in data)
+
+    def train(self):
+        if self.rank == 0:
+            print(" >> Training model %s." % self.args.model)
+        for self.epoch in range(self.args.ep):
+            for i, data in enumerate(self.dataloader['train']):
+                self.global_step += 1
+                self.set_input(data)
+                self.optimize_params()
+                if self.global_step % self.args.freq == 0:
+                    if hasattr(self, "test"):
+                        self.test()
+                    self.update_summary()
+            if self.rank == 0:
+                print("[TRAIN Epoch %d/%d] step %d %s" % (self.epoch + 1, self.args.ep, self.global_step,
+                                                          {k: round(float(v), 5) for k, v in self.errors().items()}))
+        if self.rank == 0:
+            print(" >> Training model %s.[Done]" % self.args.model)
+
+    def errors(self):
+        """Loss scalars of the last step as Python floats (ONE device sync for all of them; the reference pays one
+        ``.item()`` sync per scalar, models/mygannet.py:314-342)."""
+        if not self.errors_dict:
+            return {}
+        keys = list(self.errors_dict.keys())
+        vals = torch.stack([self.errors_dict[k].detach().float().reshape(()) if torch.is_tensor(self.errors_dict[k])
+                            else torch.tensor(float(self.errors_dict[k]), device=self.device) for k in keys]).tolist()
+        return dict(zip(keys, vals))
+
+    def update_summary(self):
+        if self.writer is None:
+            return
+        for t, e in self.errors().items():
+            spk = t.rsplit('/', 1)
+            self.writer.add_scalars(spk[0], {spk[1]: e}, self.global_step)
+        for t, s in self.score_dict.items():
+            self.writer.add_scalar(t, s, self.global_step)

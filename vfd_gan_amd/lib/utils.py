@@ -1,0 +1,70 @@
+"""Host-side mirror of the hot-path helpers of the reference's lib/utils.py (weights_init :51-56, l2_loss :59-63,
+weighted_bce :65-71, gray2rgb :91-92, threshold :149-152, fix_model_state_dict :15-22).  The cv2 / tensorboard
+helpers of that file (video_to_flow, morphology_proc, update_summary ...) are out of scope."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from ..functional import ClTensor
+
+
+def fix_model_state_dict(state_dict):
+    """Strip the ``module.`` prefix DataParallel checkpoints carry (reference lib/utils.py:15-22; the reference
+    forgets to import OrderedDict there)."""
+    new_state_dict = OrderedDict()
+    for k, v in state_dict.items():
+        name = k[7:] if k.startswith("module.") else k
+        new_state_dict[name] = v
+    return new_state_dict
+
+
+def weights_init(m):
+    """Reference lib/utils.py:51-56: Conv3d.weight ~ N(0, .02); BatchNorm3d.weight ~ N(1, .02), bias = 0.
+    ConvTranspose3d, Linear, BatchNorm1d and all 2-D layers are NOT touched (isinstance semantics)."""
+    if isinstance(m, nn.Conv3d):
+        m.weight.data.normal_(0.0, 0.02)
+        F.invalidate_weight_cache()
+    elif isinstance(m, nn.BatchNorm3d):
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def weights_init_dcgan(m):
+    """Upstream GANomaly initialiser (the reference imports it from a lib.networks module that is not in its tree,
+    models/ganomaly.py:18): Conv* ~ N(0, .02); BatchNorm* weight ~ N(1, .02), bias 0.  Build-declared default."""
+    classname = m.__class__.__name__
+    if classname.find("Conv") != -1:
+        m.weight.data.normal_(0.0, 0.02)
+        F.invalidate_weight_cache()
+    elif classname.find("BatchNorm") != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def _cl(x):
+    return x if isinstance(x, ClTensor) else F.to_cl(x)
+
+
+def l2_loss(input, target, size_average=True):
+    """Reference lib/utils.py:59-63.  Returns a 0-d float32 device tensor with an autograd edge."""
+    if not size_average:
+        raise NotImplementedError("size_average=False is never used on the hot path")
+    return F.l2_loss(_cl(input), _cl(target))
+
+
+def weighted_bce(input, target, pos_weight=2):
+    """Reference lib/utils.py:65-71 (pos_weight weighs the NEGATIVE class; the clamp upper bound is 1.0 in fp32)."""
+    return F.weighted_bce(_cl(input), _cl(target), pos_weight)
+
+
+def gray2rgb(video):
+    """Reference lib/utils.py:91-92."""
+    return F.gray2rgb(_cl(video))
+
+
+def threshold(data):
+    """Reference lib/utils.py:149-152 (summaries only; off the numerical path)."""
+    t = data.to_torch() if isinstance(data, ClTensor) else data
+    return (t > 0.5).float()

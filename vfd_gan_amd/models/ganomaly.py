@@ -1,0 +1,277 @@
+"""GANomaly nets and training step on HIP kernels, behind the surface of the reference's models/ganomaly.py.
+
+Reference: Encoder :24-76, Decoder :79-133, NetD :137-157, NetG :160-175, step :459-519.  That file is the upstream
+2-D image GANomaly (dead code in the reference: it imports lib.networks / lib.visualizer / lib.loss, which are not
+in its tree, and reads options lib/args.py never defines).  Here it is wired to the clip contract of the rest of
+the repo: a (B,3,T,H,W) clip is folded to B*T frames (free reshape in channels-last) and the 2-D nets run on them.
+
+Generalisation (SURVEY.md sections 0, 8d): the reference pyramid only works for power-of-two ``isize``
+(``Decoder.__init__`` does not terminate at 112 / 224).  Here the pyramid halves while ``csize >= 8`` and the final
+encoder conv / initial decoder conv-transpose use kernel = the remaining extent (4 for powers of two — where this
+reduces EXACTLY to the reference, same modules, same state_dict keys — and 7 for 112 / 224).
+"""
+import types
+
+import torch
+import torch.nn as tnn
+
+from .. import functional as F
+from .. import nn as hnn
+from .. import optim as hoptim
+from .. import dist as vdist
+from ..functional import ClTensor
+from ..lib.train_gan import GANBaseModel
+from ..lib.utils import weights_init_dcgan
+
+
+def _pyramid_floor(isize):
+    """Spatial extent at which the encoder pyramid stops (4 for powers of two, as in the reference)."""
+    csize = isize // 2
+    while csize >= 8 and csize % 2 == 0:
+        csize //= 2
+    return csize
+
+
+class Encoder(tnn.Module):
+    """DCGAN encoder (reference models/ganomaly.py:24-76; same signature and child names)."""
+
+    def __init__(self, isize, nz, nc, ndf, ngpu, n_extra_layers=0, add_final_conv=True):
+        super(Encoder, self).__init__()
+        self.ngpu = ngpu
+        assert isize % 16 == 0, "isize has to be a multiple of 16"
+
+        main = hnn.Sequential()
+        main.add_module('initial-conv-{0}-{1}'.format(nc, ndf), hnn.Conv2d(nc, ndf, 4, 2, 1, bias=False))
+        main.add_module('initial-relu-{0}'.format(ndf), hnn.LeakyReLU(0.2, inplace=True))
+        csize, cndf = isize // 2, ndf
+
+        for t in range(n_extra_layers):
+            main.add_module('extra-layers-{0}-{1}-conv'.format(t, cndf), hnn.Conv2d(cndf, cndf, 3, 1, 1, bias=False))
+            main.add_module('extra-layers-{0}-{1}-batchnorm'.format(t, cndf), hnn.BatchNorm2d(cndf))
+            main.add_module('extra-layers-{0}-{1}-relu'.format(t, cndf), hnn.LeakyReLU(0.2, inplace=True))
+
+        floor = _pyramid_floor(isize)
+        while csize > floor:
+            in_feat, out_feat = cndf, cndf * 2
+            main.add_module('pyramid-{0}-{1}-conv'.format(in_feat, out_feat),
+                            hnn.Conv2d(in_feat, out_feat, 4, 2, 1, bias=False))
+            main.add_module('pyramid-{0}-batchnorm'.format(out_feat), hnn.BatchNorm2d(out_feat))
+            main.add_module('pyramid-{0}-relu'.format(out_feat), hnn.LeakyReLU(0.2, inplace=True))
+            cndf = cndf * 2
+            csize = csize // 2
+
+        if add_final_conv:
+            main.add_module('final-{0}-{1}-conv'.format(cndf, 1), hnn.Conv2d(cndf, nz, csize, 1, 0, bias=False))
+
+        self.main = main
+
+    def forward(self, input):
+        return _io(self.main, input)
+
+
+class Decoder(tnn.Module):
+    """DCGAN decoder (reference models/ganomaly.py:79-133)."""
+
+    def __init__(self, isize, nz, nc, ngf, ngpu, n_extra_layers=0):
+        super(Decoder, self).__init__()
+        self.ngpu = ngpu
+        assert isize % 16 == 0, "isize has to be a multiple of 16"
+
+        floor = _pyramid_floor(isize)
+        cngf, tisize = ngf // 2, floor
+        while tisize != isize:
+            cngf = cngf * 2
+            tisize = tisize * 2
+
+        main = hnn.Sequential()
+        main.add_module('initial-{0}-{1}-convt'.format(nz, cngf), hnn.ConvTranspose2d(nz, cngf, floor, 1, 0, bias=False))
+        main.add_module('initial-{0}-batchnorm'.format(cngf), hnn.BatchNorm2d(cngf))
+        main.add_module('initial-{0}-relu'.format(cngf), hnn.ReLU(True))
+
+        csize = floor
+        while csize < isize // 2:
+            main.add_module('pyramid-{0}-{1}-convt'.format(cngf, cngf // 2),
+                            hnn.ConvTranspose2d(cngf, cngf // 2, 4, 2, 1, bias=False))
+            main.add_module('pyramid-{0}-batchnorm'.format(cngf // 2), hnn.BatchNorm2d(cngf // 2))
+            main.add_module('pyramid-{0}-relu'.format(cngf // 2), hnn.ReLU(True))
+            cngf = cngf // 2
+            csize = csize * 2
+
+        for t in range(n_extra_layers):
+            main.add_module('extra-layers-{0}-{1}-conv'.format(t, cngf), hnn.Conv2d(cngf, cngf, 3, 1, 1, bias=False))
+            main.add_module('extra-layers-{0}-{1}-batchnorm'.format(t, cngf), hnn.BatchNorm2d(cngf))
+            main.add_module('extra-layers-{0}-{1}-relu'.format(t, cngf), hnn.ReLU(True))
+
+        main.add_module('final-{0}-{1}-convt'.format(cngf, nc), hnn.ConvTranspose2d(cngf, nc, 4, 2, 1, bias=False))
+        main.add_module('final-{0}-tanh'.format(nc), hnn.Tanh())
+        self.main = main
+
+    def forward(self, input):
+        return _io(self.main, input)
+
+
+def _io(fn, x):
+    """Run `fn` on a ClTensor; accept / return plain (N,C,H,W) float tensors at the user boundary."""
+    if isinstance(x, ClTensor):
+        return fn(x)
+    y = fn(F.to_cl(x))
+    return y.to_torch()
+
+
+class NetD(tnn.Module):
+    """Discriminator (reference models/ganomaly.py:137-157): Encoder(nz=1) split into features + classifier."""
+
+    def __init__(self, opt):
+        super(NetD, self).__init__()
+        model = Encoder(opt.isize, 1, opt.nc, opt.ngf, opt.ngpu, opt.extralayers)
+        layers = list(model.main.children())
+
+        self.features = hnn.Sequential(*layers[:-1])
+        self.classifier = hnn.Sequential(layers[-1])
+        self.classifier.add_module('Sigmoid', hnn.Sigmoid())
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        xc = F.to_cl(x) if plain else x
+        features = self.features(xc)
+        classifier = self.classifier(features)          # (N,1,1,1) block == view(-1,1).squeeze(1)
+        if plain:
+            return classifier.to_torch().view(-1, 1).squeeze(1), features.to_torch()
+        return classifier, features
+
+
+class NetG(tnn.Module):
+    """Generator (reference models/ganomaly.py:160-175): encoder -> decoder -> encoder."""
+
+    def __init__(self, opt):
+        super(NetG, self).__init__()
+        self.encoder1 = Encoder(opt.isize, opt.nz, opt.nc, opt.ngf, opt.ngpu, opt.extralayers)
+        self.decoder = Decoder(opt.isize, opt.nz, opt.nc, opt.ngf, opt.ngpu, opt.extralayers)
+        self.encoder2 = Encoder(opt.isize, opt.nz, opt.nc, opt.ngf, opt.ngpu, opt.extralayers)
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        xc = F.to_cl(x) if plain else x
+        latent_i = self.encoder1(xc)
+        gen_imag = self.decoder(latent_i)
+        latent_o = self.encoder2(gen_imag)
+        if plain:
+            return gen_imag.to_torch(), latent_i.to_torch(), latent_o.to_torch()
+        return gen_imag, latent_i, latent_o
+
+
+# Upstream GANomaly option defaults.  They are NOT citeable in the reference tree (models/ganomaly.py reads an
+# options object that lib/args.py never defines), so they are declared here as this build's defaults.
+GANOMALY_DEFAULTS = dict(nz=100, ngf=64, nc=3, ngpu=1, extralayers=0, w_adv=1.0, w_con=50.0, w_enc=1.0,
+                         lr=2e-4, beta1=0.5)
+
+
+def make_opt(args=None, **over):
+    d = dict(GANOMALY_DEFAULTS)
+    if args is not None:
+        d.update(isize=args.isize, nc=getattr(args, "ich", 3), batchsize=args.batchsize)
+    d.update(over)
+    return types.SimpleNamespace(**d)
+
+
+def fold_frames(x):
+    """(B,C,T,H,W) clip block -> B*T frames (B*T,C,H,W): a free view in channels-last."""
+    t = x.t
+    n, d, h, w, cp = t.shape
+    return ClTensor(t.reshape(n * d, 1, h, w, cp), x.C, 2)
+
+
+class Ganomaly(GANBaseModel):
+    """Training step of reference models/ganomaly.py:459-519 (forward_g, forward_d, backward_g, backward_d,
+    optimize_params, reinit_d) with the 4-tuple clip contract of lib/train_gan.py:69."""
+
+    @property
+    def name(self):
+        return 'Ganomaly'
+
+    def __init__(self, args, dataloader, opt=None):
+        super(Ganomaly, self).__init__(args, dataloader)
+        self.opt = opt if opt is not None else make_opt(args)
+        self.netg = NetG(self.opt).to(self.device)
+        self.netd = NetD(self.opt).to(self.device)
+        self.netg.apply(weights_init_dcgan)
+        self.netd.apply(weights_init_dcgan)
+        vdist.broadcast_module(self.netg)
+        vdist.broadcast_module(self.netd)
+
+        self.l_adv = F.l2_loss
+        self.l_con = F.l1_loss
+        self.l_enc = F.l2_loss
+        self.l_bce = F.bce_loss
+        self.real_label, self.fake_label = 1.0, 0.0
+
+        self.netg.train()
+        self.netd.train()
+        self.optimizer_d = hoptim.Adam(self.netd.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        self.optimizer_g = hoptim.Adam(self.netg.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        self.reducer_g = vdist.GradReducer.for_optimizer(self.optimizer_g)
+        self.reducer_d = vdist.GradReducer.for_optimizer(self.optimizer_d)
+
+    # ---- reference-named phases ------------------------------------------------------------------------------
+    def set_input(self, data):
+        super(Ganomaly, self).set_input(data)
+        self.x = fold_frames(F.to_cl(self.input))   # frames, channels-last, compute dtype
+
+    def forward_g(self):
+        self.fake, self.latent_i, self.latent_o = self.netg(self.x)
+
+    def forward_d(self):
+        self.pred_real, self.feat_real = self.netd(self.x)
+        self.pred_fake, self.feat_fake = self.netd(self.fake.detach())
+
+    def backward_g(self):
+        # The reference lets this backward also deposit gradients into netD's parameters and then discards them
+        # (optimizer_d.zero_grad() at :515 runs before they are ever used).  Freezing netD here skips exactly that
+        # discarded filter-gradient work; everything that survives the step is unchanged.
+        for p in self.netd.parameters():
+            p.requires_grad_(False)
+        self.reducer_d.enabled = False
+        try:
+            self.err_g_adv = self.l_adv(self.netd(self.x)[1], self.netd(self.fake)[1])
+            self.err_g_con = self.l_con(self.fake, self.x)
+            self.err_g_enc = self.l_enc(self.latent_o, self.latent_i)
+            self.err_g = self.err_g_adv * self.opt.w_adv + \
+                         self.err_g_con * self.opt.w_con + \
+                         self.err_g_enc * self.opt.w_enc
+            self.err_g.backward()
+        finally:
+            for p in self.netd.parameters():
+                p.requires_grad_(True)
+            self.reducer_d.enabled = True
+        self.reducer_g.finish()
+
+    def backward_d(self):
+        self.err_d_real = self.l_bce(self.pred_real, self.real_label)
+        self.err_d_fake = self.l_bce(self.pred_fake, self.fake_label)
+        self.err_d = (self.err_d_real + self.err_d_fake) * 0.5
+        self.err_d.backward()
+        self.reducer_d.finish()
+
+    def reinit_d(self):
+        self.netd.apply(weights_init_dcgan)
+        if self.rank == 0:
+            print('   Reloading net d')
+
+    def optimize_params(self, check_collapse=True):
+        self.forward_g()
+        self.forward_d()
+
+        self.optimizer_g.zero_grad()
+        self.backward_g()
+        self.optimizer_g.step()
+
+        self.optimizer_d.zero_grad()
+        self.backward_d()
+        self.optimizer_d.step()
+
+        self.errors_dict.update({'g/err_g/train': self.err_g, 'g/err_g_adv/train': self.err_g_adv,
+                                 'g/err_g_con/train': self.err_g_con, 'g/err_g_enc/train': self.err_g_enc,
+                                 'd/err_d/train': self.err_d, 'd/err_d_real/train': self.err_d_real,
+                                 'd/err_d_fake/train': self.err_d_fake})
+        if check_collapse and self.err_d.item() < 1e-5:   # reference :519 (one host sync per step, as there)
+            self.reinit_d()

@@ -1,0 +1,230 @@
+"""HIP-backed layers with the constructor signatures, attribute names and ``state_dict`` keys of the torch.nn
+layers the reference builds its nets from.
+
+Each class SUBCLASSES its torch.nn counterpart — parameters, buffers, initialisation, ``isinstance`` checks
+(the reference's ``weights_init`` dispatches on ``isinstance(m, nn.Conv3d)``, lib/utils.py:51-56) and
+checkpoint compatibility come from the parent — and overrides only ``forward``, which runs hand-written HIP
+kernels on a :class:`~vfd_gan_amd.functional.ClTensor` (channels-last, bf16/f32).  There is no torch fallback:
+calling these layers with CPU tensors raises.
+"""
+import torch
+import torch.nn as tnn
+
+from . import _lib
+from . import functional as F
+from .functional import ClTensor
+
+
+def _need_cl(x, who):
+    if not isinstance(x, ClTensor):
+        raise TypeError("%s expects a ClTensor (use vfd_gan_amd.functional.to_cl at the network entry), got %s"
+                        % (who, type(x).__name__))
+    return x
+
+
+def _act_of(m):
+    """(act code, slope) of an activation module, or None."""
+    if isinstance(m, tnn.LeakyReLU):
+        return _lib.ACT_LRELU, float(m.negative_slope)
+    if isinstance(m, tnn.ReLU):
+        return _lib.ACT_LRELU, 0.0
+    if isinstance(m, tnn.Sigmoid):
+        return _lib.ACT_SIGMOID, 0.0
+    if isinstance(m, tnn.Tanh):
+        return _lib.ACT_TANH, 0.0
+    return None
+
+
+# ---- convolution family ------------------------------------------------------------------------------------
+class _ConvMixin:
+    _transposed = False
+
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None):
+        _need_cl(x, type(self).__name__)
+        if self.groups != 1 or any(d != 1 for d in self.dilation):
+            raise NotImplementedError("groups/dilation are not used by the reference nets")
+        if self.padding_mode != "zeros":
+            raise NotImplementedError("padding_mode %r" % (self.padding_mode,))
+        op = self.output_padding if self._transposed else 0
+        return F.conv(x, self.weight, self.bias, self.stride, self.padding, op, self._transposed, act, slope, stats)
+
+
+class Conv3d(_ConvMixin, tnn.Conv3d):
+    pass
+
+
+class Conv2d(_ConvMixin, tnn.Conv2d):
+    pass
+
+
+class ConvTranspose3d(_ConvMixin, tnn.ConvTranspose3d):
+    _transposed = True
+
+
+class ConvTranspose2d(_ConvMixin, tnn.ConvTranspose2d):
+    _transposed = True
+
+
+class Linear(tnn.Linear):
+    """nn.Linear on an (N, F) block.  When the input is a flattened (N,C,D,H,W) block (``x.view(N, -1)`` in the
+    reference, models/anogan.py:115, models/mygannet.py:158,191) pass the un-flattened ClTensor: the layer then
+    runs as a convolution whose kernel covers the whole block, with the weight viewed as [out, C, D, H, W] —
+    identical arithmetic, no layout shuffle."""
+
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0):
+        _need_cl(x, "Linear")
+        n, d, h, w, _ = x.t.shape
+        feat = x.C * d * h * w
+        if feat != self.in_features:
+            raise RuntimeError("Linear: input has %d features, expected %d (shape %s)" % (feat, self.in_features, x.shape))
+        if d * h * w == 1:
+            y = F.conv(ClTensor(x.t, x.C, 0), self.weight, self.bias, 1, 0, 0, False, act, slope)
+        else:
+            wv = self.weight.view(self.out_features, x.C, d, h, w)
+            y = F.conv(ClTensor(x.t, x.C, 3), wv, self.bias, 1, 0, 0, False, act, slope)
+        return ClTensor(y.t, self.out_features, 0)
+
+
+# ---- normalisation ---------------------------------------------------------------------------------------------
+class _BatchNormMixin:
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, sums=None):
+        _need_cl(x, type(self).__name__)
+        if x.C != self.num_features:
+            raise RuntimeError("BatchNorm: %d channels, expected %d" % (x.C, self.num_features))
+        if not self.training:
+            raise NotImplementedError("eval-mode BatchNorm is off the training hot path (SURVEY.md 8f N2)")
+        if self.momentum is None:
+            raise NotImplementedError("cumulative-average BatchNorm (momentum=None)")
+        if self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums)
+
+
+class BatchNorm3d(_BatchNormMixin, tnn.BatchNorm3d):
+    pass
+
+
+class BatchNorm2d(_BatchNormMixin, tnn.BatchNorm2d):
+    pass
+
+
+class BatchNorm1d(_BatchNormMixin, tnn.BatchNorm1d):
+    pass
+
+
+# ---- activations / pooling / resampling / dropout -----------------------------------------------------------------
+class LeakyReLU(tnn.LeakyReLU):
+    def forward(self, x):
+        return F.activation(_need_cl(x, "LeakyReLU"), _lib.ACT_LRELU, self.negative_slope)
+
+
+class ReLU(tnn.ReLU):
+    def forward(self, x):
+        return F.activation(_need_cl(x, "ReLU"), _lib.ACT_LRELU, 0.0)
+
+
+class Sigmoid(tnn.Sigmoid):
+    def forward(self, x):
+        return F.activation(_need_cl(x, "Sigmoid"), _lib.ACT_SIGMOID)
+
+
+class Tanh(tnn.Tanh):
+    def forward(self, x):
+        return F.activation(_need_cl(x, "Tanh"), _lib.ACT_TANH)
+
+
+class AvgPool3d(tnn.AvgPool3d):
+    def forward(self, x):
+        _need_cl(x, "AvgPool3d")
+        k = F._triple(self.kernel_size, 3, 1)
+        s = F._triple(self.stride if self.stride is not None else self.kernel_size, 3, 1)
+        in_dhw = tuple(x.t.shape[1:4])
+        # kernel == stride (ordinary pooling) or a pool that spans the whole extent (the "global" pools of
+        # SDisc / TDisc, stride 1, output extent 1)
+        for i in range(3):
+            if not (k[i] == s[i] or k[i] == in_dhw[i]):
+                raise NotImplementedError("AvgPool3d kernel %s stride %s on %s" % (k, s, in_dhw))
+        if F._triple(self.padding, 3, 0) != (0, 0, 0):
+            raise NotImplementedError("padded AvgPool3d")
+        return F.avg_pool(x, k)
+
+
+class Upsample(tnn.Upsample):
+    def forward(self, x):
+        _need_cl(x, "Upsample")
+        if not (self.mode == "trilinear" and self.align_corners and float(self.scale_factor) == 2.0):
+            raise NotImplementedError("only Upsample(scale_factor=2, mode='trilinear', align_corners=True)")
+        return F.upsample_trilinear2x(x)
+
+
+class Dropout(tnn.Dropout):
+    def forward(self, x):
+        return F.dropout(_need_cl(x, "Dropout"), self.p, self.training)
+
+
+# ---- Sequential with peephole fusion ---------------------------------------------------------------------------------
+_CONVS = (Conv3d, Conv2d, ConvTranspose3d, ConvTranspose2d, Linear)
+_BNS = (BatchNorm3d, BatchNorm2d, BatchNorm1d)
+
+
+def run_fused(mods, x):
+    """Run a list of HIP-backed layers, fusing conv->act into the conv epilogue, BatchNorm->act into one
+    normalise+activate pass, and (bf16) conv->BatchNorm statistics into the conv epilogue."""
+    i, n = 0, len(mods)
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        if isinstance(m, _CONVS):
+            a = _act_of(nxt) if nxt is not None else None
+            if a is not None:
+                x = m(x, act=a[0], slope=a[1])
+                i += 2
+                continue
+            if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and use_epilogue_stats(x):
+                sums = torch.zeros(2 * F.cpad(m.out_channels), dtype=torch.float32, device=x.t.device)
+                x = m(x, stats=sums)
+                a = _act_of(mods[i + 2]) if i + 2 < n else None
+                if a is not None:
+                    x = nxt(x, act=a[0], slope=a[1], sums=sums)
+                    i += 3
+                else:
+                    x = nxt(x, sums=sums)
+                    i += 2
+                continue
+            x = m(x)
+            i += 1
+            continue
+        if isinstance(m, _BNS):
+            a = _act_of(nxt) if nxt is not None else None
+            if a is not None:
+                x = m(x, act=a[0], slope=a[1])
+                i += 2
+                continue
+        x = m(x)
+        i += 1
+    return x
+
+
+_EPILOGUE_STATS = {"mode": "auto"}
+
+
+def set_epilogue_stats(mode):
+    """'auto' (bf16: BatchNorm statistics come from the conv epilogue; f32: separate exact pass), 'on', 'off'."""
+    assert mode in ("auto", "on", "off")
+    _EPILOGUE_STATS["mode"] = mode
+
+
+def use_epilogue_stats(x):
+    mode = _EPILOGUE_STATS["mode"]
+    if mode == "auto":
+        return x.t.dtype == torch.bfloat16
+    return mode == "on"
+
+
+class Sequential(tnn.Sequential):
+    """nn.Sequential (same child naming, hence same state_dict keys) executed through :func:`run_fused`."""
+
+    def forward(self, x):
+        return run_fused(list(self), x)

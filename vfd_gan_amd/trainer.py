@@ -1,0 +1,44 @@
+"""Dispatcher with the behaviour of the reference's trainer.py:7-56 for the GAN models.
+
+``python -m vfd_gan_amd.trainer --model {mygan,anogan,ganomaly} ...`` (or under torchrun for one process per GPU:
+the reference's ``--gpu 0,1`` DataParallel is replaced by RCCL data parallelism, vfd_gan_amd/dist.py).  The
+supervised baselines (c2plus1d / xception / clstm -> lib/train_stcnn.py) are outside the hot path
+ and are rejected with the reference's own "is None" message.
+"""
+from __future__ import print_function
+
+from . import dist as vdist
+from . import functional as F
+from .lib.args import Args
+
+
+def main(args):
+    # -- DATA LOAD --
+    from .lib.data import DataLoader
+    dataloader = DataLoader(args, rank=vdist.rank()).load_data()
+
+    # -- MODEL LOAD --
+    if vdist.rank() == 0:
+        print("--Load model--")
+    if args.model == 'mygan':
+        from .models.mygannet import MyGAN
+        model = MyGAN(args, dataloader)
+    elif args.model == 'anogan':
+        from .models.anogan import AnoGAN
+        model = AnoGAN(args, dataloader)
+    elif args.model == 'ganomaly':
+        from .models.ganomaly import Ganomaly
+        model = Ganomaly(args, dataloader)
+    else:
+        print("\n %s is None." % (args.model))
+        exit()
+
+    model.train()
+    return model
+
+
+if __name__ == '__main__':
+    args = Args().parse()
+    vdist.init_from_env()
+    F.set_compute_dtype(args.dtype)
+    main(args)
