@@ -91,7 +91,11 @@ int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T
  * sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
  * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106).                  */
 int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
-                     float* stats, void* stream);
+                     float* stats, void* ws, size_t ws_bytes, void* stream);
+/* Scratch bytes vfd_conv_forward wants for `d` (0 for most shapes).  Convolutions with few output pixels and a
+ * long reduction (ganomaly Encoder final conv / NetD classifier: 512 pixels x K=25088) split K over workgroups
+ * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
+int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes);
 
 /* Filter gradient.  Computes, for the conv described by `d` (same desc as forward),
  *     dWp[r][t][c] = sum_{n,q} S[n,q][r] * G[n, q*s-p+t][c]

@@ -72,7 +72,7 @@ def test_ganomaly_step_parity(dt, S, ngf, extra, dev, tmp_path):
                     # Adam's early steps move every weight by ~lr whatever the gradient's size, so a weight whose
                     # gradient is ~0 amplifies rounding noise: state the tolerance in units of lr per step taken
                     d = (v.detach().cpu().double() - r.detach().double()).abs()
-                    assert float(d.max()) <= (0.5 if f32 else 2.01) * lr * (it + 1), (it, k, float(d.max()))
+                    assert float(d.max()) <= (0.5 if f32 else 6.0) * lr * (it + 1), (it, k, float(d.max()))
                     assert float(d.mean()) <= (0.01 if f32 else 0.35) * lr * (it + 1), (it, k, float(d.mean()))
 
 

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv family on the bench workload's geometries (ganomaly 16x112x112, 512 frames):
+forward, data gradient and filter gradient of every distinct layer, TFLOP/s against the bf16 MFMA peak."""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from vfd_gan_amd import _lib, functional as F  # noqa: E402
+
+LAYERS = [
+    # name, Cin, Cout, H(in), k, s, p, transposed
+    ("enc.init 3->64 k4s2 @112", 3, 64, 112, 4, 2, 1, False),
+    ("enc.pyr 64->128 k4s2 @56", 64, 128, 56, 4, 2, 1, False),
+    ("enc.pyr 128->256 k4s2 @28", 128, 256, 28, 4, 2, 1, False),
+    ("enc.pyr 256->512 k4s2 @14", 256, 512, 14, 4, 2, 1, False),
+    ("enc.final 512->100 k7 @7", 512, 100, 7, 7, 1, 0, False),
+    ("D.cls 512->1 k7 @7", 512, 1, 7, 7, 1, 0, False),
+    ("dec.init 100->512 k7 convT @1", 100, 512, 1, 7, 1, 0, True),
+    ("dec.pyr 512->256 convT @7", 512, 256, 7, 4, 2, 1, True),
+    ("dec.pyr 256->128 convT @14", 256, 128, 14, 4, 2, 1, True),
+    ("dec.pyr 128->64 convT @28", 128, 64, 28, 4, 2, 1, True),
+    ("dec.final 64->3 convT @56", 64, 3, 56, 4, 2, 1, True),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda", 0)
+    lib = _lib.load()
+    N = a.frames
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    print("%-34s %10s %8s | %10s %8s | %10s %8s" % ("layer", "fwd us", "TF/s", "dgrad us", "TF/s", "wgrad us", "TF/s"))
+    for name, cin, cout, h, k, s, p, tr in LAYERS:
+        if a.only and a.only not in name:
+            continue
+        ho = (h - 1) * s - 2 * p + k if tr else (h + 2 * p - k) // s + 1
+        x = torch.randn(N, 1, h, h, F.cpad(cin), device=dev).to(dt)
+        x[..., cin:] = 0
+        gy = torch.randn(N, 1, ho, ho, F.cpad(cout), device=dev).to(dt)
+        gy[..., cout:] = 0
+        w = torch.nn.Parameter(torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=dev) * 0.05)
+        T = k * k
+        A, B = (cin, cout) if tr else (cout, cin)
+        pk_f = F._packed_filter(w, dt, bool(tr), A, B, T)
+        pk_d = F._packed_filter(w, dt, not tr, A, B, T)
+        y = torch.empty_like(gy)
+        gx = torch.empty_like(x)
+        d_f = F._make_desc(N, (1, h, h), cin, (1, ho, ho), cout, (1, k, k), (1, s, s), (0, p, p), tr, dt)
+        d_d = F._make_desc(N, (1, ho, ho), cout, (1, h, h), cin, (1, k, k), (1, s, s), (0, p, p), not tr, dt)
+        nsplit, nbytes = ctypes.c_int32(), ctypes.c_size_t()
+        _lib.check(lib.vfd_wgrad_workspace(ctypes.byref(d_f), ctypes.byref(nsplit), ctypes.byref(nbytes)))
+        ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        gw = torch.empty_like(w)
+        st = _lib.stream()
+        flops = 2.0 * N * (h * h if tr else ho * ho) * T * cin * cout
+        def wsp(d):
+            need = ctypes.c_size_t()
+            _lib.check(lib.vfd_conv_workspace(ctypes.byref(d), 0, ctypes.byref(need)))
+            return torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev), need.value
+        wf, nf = wsp(d_f)
+        wd, ndb = wsp(d_d)
+        t_f = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_f), x.data_ptr(), pk_f.data_ptr(), 0, y.data_ptr(), 0, wf.data_ptr(), nf, st), a.iters)
+        t_d = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_d), gy.data_ptr(), pk_d.data_ptr(), 0, gx.data_ptr(), 0, wd.data_ptr(), ndb, st), a.iters)
+
+        def wg():
+            lib.vfd_conv_wgrad(ctypes.byref(d_f), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, st)
+            lib.vfd_wgrad_reduce(ctypes.byref(d_f), ws.data_ptr(), gw.data_ptr(), 0.0, st)
+        t_w = timeit(wg, a.iters)
+        tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
+        print("%-34s %10.1f %8.1f | %10.1f %8.1f | %10.1f %8.1f   (split %d)" % (name, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6,
+                                                                   t_w, flops / t_w / 1e6, nsplit.value))
+    print("totals us:", {k: round(v, 1) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -29,7 +29,7 @@ static Tiling make_tiling(long long rows, int C, int max_gy) {
   t.rows_per_block = (rows + gy - 1) / gy;
   return t;
 }
-constexpr int BN_MAX_BLOCKS = 2048;
+constexpr int BN_MAX_BLOCKS = 1024;
 
 // ---- statistics: per-workgroup (count, mean, M2) per channel ----------------------------------------------
 template <typename T>
@@ -111,23 +111,41 @@ __device__ __forceinline__ void bn_write_stats(int c, double n, double mean, dou
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float eps, float momentum, float* mean_o,
-                                   float* rstd_o, float* rmean, float* rvar) {
+// One workgroup per 32 channels: 8 part-lanes per channel walk the workgroup partials, Chan-merge in LDS.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float eps,
+                                                          float momentum, float* mean_o, float* rstd_o, float* rmean,
+                                                          float* rvar) {
   const int Cp = (C + 7) & ~7;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double n = 0, mean = 0, m2 = 0;
-  for (int j = 0; j < nparts; ++j) {
-    const float* src = part + (size_t)j * 3 * Cp;
-    const double nb = src[c];
-    if (nb > 0) {
-      const double nt = n + nb, d = (double)src[Cp + c] - mean;
-      mean += d * (nb / nt);
-      m2 += (double)src[2 * Cp + c] + d * d * (n * nb / nt);
-      n = nt;
+  if (c < C) {
+    for (int j = pl; j < nparts; j += 8) {
+      const float* src = part + (size_t)j * 3 * Cp;
+      const double nb = src[c];
+      if (nb > 0) {
+        const double nt = n + nb, d = (double)src[Cp + c] - mean;
+        mean += d * (nb / nt);
+        m2 += (double)src[2 * Cp + c] + d * d * (n * nb / nt);
+        n = nt;
+      }
     }
   }
-  bn_write_stats(c, n, mean, m2, eps, momentum, mean_o, rstd_o, rmean, rvar);
+  __shared__ double sh[3][8][32];
+  sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    for (int j = 1; j < 8; ++j) {
+      const double nb = sh[0][j][cl];
+      if (nb > 0) {
+        const double nt = n + nb, d = sh[1][j][cl] - mean;
+        mean += d * (nb / nt);
+        m2 += sh[2][j][cl] + d * d * (n * nb / nt);
+        n = nt;
+      }
+    }
+    bn_write_stats(c, n, mean, m2, eps, momentum, mean_o, rstd_o, rmean, rvar);
+  }
 }
 
 __global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long rows, int C, float eps, float momentum,
@@ -227,17 +245,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* dgamma,
+                                                              float* dbeta) {
   const int Cp = (C + 7) & ~7;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double sg = 0, sgx = 0;
-  for (int j = 0; j < nparts; ++j) {
-    sg += part[(size_t)j * 2 * Cp + c];
-    sgx += part[(size_t)j * 2 * Cp + Cp + c];
+  if (c < C)
+    for (int j = pl; j < nparts; j += 8) {
+      sg += part[(size_t)j * 2 * Cp + c];
+      sgx += part[(size_t)j * 2 * Cp + Cp + c];
+    }
+  __shared__ double sh[2][8][32];
+  sh[0][pl][cl] = sg; sh[1][pl][cl] = sgx;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    for (int j = 1; j < 8; ++j) { sg += sh[0][j][cl]; sgx += sh[1][j][cl]; }
+    dbeta[c] = (float)sg;
+    dgamma[c] = (float)sgx;
   }
-  dbeta[c] = (float)sg;
-  dgamma[c] = (float)sgx;
 }
 
 template <typename T>
@@ -297,7 +323,7 @@ extern "C" int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float
   else
     hipLaunchKernelGGL(bn_partial_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, part, (long long)rows, C, t.TX, t.rows_per_block);
   VFD_CHECK_LAUNCH("bn_partial");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), part, t.gy, C, eps, momentum, mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), part, t.gy, C, eps, momentum, mean,
                      rstd, running_mean, running_var);
   VFD_CHECK_LAUNCH("bn_finalize");
   return VFD_OK;
@@ -340,7 +366,7 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
   else
     hipLaunchKernelGGL(bn_act_bwd_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
   VFD_CHECK_LAUNCH("bn_act_bwd_partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, part, t.gy, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, t.gy, C, dgamma, dbeta);
   VFD_CHECK_LAUNCH("bn_bwd_finalize");
   const Tiling ta = make_tiling(rows, C, 8192);
   dim3 grid2(ta.gx, ta.gy);

@@ -33,6 +33,8 @@ struct ConvP {
   int Kw;  // packed filter row length = kd*kh*kw*Cip
   int act;
   float slope;
+  int ksplit;   // >1: K range split over blockIdx.z, raw f32 partial tiles go to ws[ksplit][M][Cop]
+  float* ws;
 };
 
 struct DimClass {  // per-dimension description of the taps of one output class
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   const int wave_p0 = (wave / WAVES_C) * (NJ * 16);
 
   // ---- output class of this workgroup --------------------------------------------------------------
-  int cls = blockIdx.z;
+  int cls = blockIdx.z / p.ksplit;
+  const int ksl = blockIdx.z - cls * p.ksplit;
   const int rw = p.transposed ? cls % p.sw : 0;
   if (p.transposed) cls /= p.sw;
   const int rh = p.transposed ? cls % p.sh : 0;
@@ -146,7 +149,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   const int n0 = blockIdx.y * TILE_C;
   const int ntaps = dd.nk * dh.nk * dw.nk;
   const int Kcls = ntaps * p.Cip;
-  const int nsteps = (Kcls + BK - 1) / BK;
+  const int nsteps_all = (Kcls + BK - 1) / BK;
+  const int steps_per = (nsteps_all + p.ksplit - 1) / p.ksplit;
+  const int s_begin = ksl * steps_per;
+  const int nsteps = max(0, min(nsteps_all - s_begin, steps_per));
 
   // ---- per-thread load bookkeeping ----------------------------------------------------------------------
   const int chunk = tid & 3;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   // position of this thread's chunk inside the flattened K axis
   int kc, td, th, tw;
   {
-    const int kflat = chunk * VEC;
+    const int kflat = s_begin * BK + chunk * VEC;
     int t = kflat / p.Cip;
     kc = kflat - t * p.Cip;
     tw = (dw.nk > 0) ? t % dw.nk : 0;
@@ -258,9 +264,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
   }
 
+  const int cq = (lane >> 4) * 4;
+  if (p.ksplit > 1) {
+    // split-K: raw partial sums, [ksplit][M][Cop] float32; bias / activation / store happen in conv_splitk_finish
+    float* slab = p.ws + (size_t)ksl * (size_t)Mcls * p.Cop;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = n0 + wave_c0 + i * 16 + cq;
+        if (m < Mcls && c < p.Cop)
+          *reinterpret_cast<float4*>(slab + (size_t)m * p.Cop + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
+
   // ---- epilogue: bias, statistics, activation, channels-last store --------------------------------------
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  const int cq = (lane >> 4) * 4;
   float ssum[NI][4], ssq[NI][4];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -320,26 +342,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   }
 }
 
+// y[m][c] = act(sum_ks ws[ks][m][c] + bias[c]) for the split-K path (regular convolutions only: out pixel == m)
+template <typename T>
+__global__ void conv_splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ bias,
+                                          long long M, int Cout, int Cop, int ksplit, int act, float slope) {
+  const int GR = Cop >> 3;
+  const long long total = M * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(i % GR);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ks = 0; ks < ksplit; ++ks) {
+      float t[8];
+      load8(ws + ((size_t)ks * M * GR + i) * 8, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      v[k] = (c < Cout) ? act_apply(v[k] + (bias != nullptr ? bias[c] : 0.f), act, slope) : 0.f;
+    }
+    store8(y + i * 8, v);
+  }
+}
+
+template <int TILE_C, int TILE_P>
+int pick_ksplit(const ConvP& p, long long M, int bk) {
+  if (p.transposed || p.stats != nullptr) return 1;
+  const long long blocks = ((M + TILE_P - 1) / TILE_P) * ((p.Cout + TILE_C - 1) / TILE_C);
+  const int nsteps = (p.Kw + bk - 1) / bk;
+  if (blocks >= 128 || nsteps < 32) return 1;
+  long long ks = 512 / blocks;
+  if (ks > nsteps / 8) ks = nsteps / 8;
+  if (ks > 64) ks = 64;
+  return ks < 2 ? 1 : (int)ks;
+}
+
 template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ>
-int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st) {
+int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
   const long long mb = (maxM + TILE_P - 1) / TILE_P;
   if (mb <= 0) return VFD_OK;
   if (mb > 0x7fffffffLL) { vfd_set_error("conv: too many pixel blocks"); return VFD_EINVAL; }
-  dim3 grid((unsigned)mb, (unsigned)((p.Cout + TILE_C - 1) / TILE_C), (unsigned)ncls);
+  ConvP q = p;
+  q.ksplit = pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * Elem<T>::VEC);
+  const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
+  if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
+  if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
+  dim3 grid((unsigned)mb, (unsigned)((p.Cout + TILE_C - 1) / TILE_C), (unsigned)(ncls * q.ksplit));
   if (grid.y > 65535u || grid.z > 65535u) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ>), grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ>), grid, dim3(256), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
+  if (q.ksplit > 1) {
+    const long long total = maxM * (p.Cop >> 3);
+    long long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, q.ws, reinterpret_cast<T*>(p.y), p.bias,
+                       maxM, p.Cout, p.Cop, q.ksplit, p.act, p.slope);
+    VFD_CHECK_LAUNCH("conv_splitk_finish");
+  }
   return VFD_OK;
 }
 
 template <typename T>
-int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st) {
-  if (p.Cout > 64) return launch_cfg<T, 2, 2, 4, 4>(p, maxM, ncls, st);   // 128 ch x 128 px
-  if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4>(p, maxM, ncls, st);   //  64 ch x 256 px
-  if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4>(p, maxM, ncls, st);   //  32 ch x 256 px
-  return launch_cfg<T, 1, 4, 1, 4>(p, maxM, ncls, st);                    //  16 ch x 256 px
+int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
+  if (p.Cout > 64) return launch_cfg<T, 2, 2, 4, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   // 128 ch x 128 px
+  if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   //  64 ch x 256 px
+  if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   //  32 ch x 256 px
+  return launch_cfg<T, 1, 4, 1, 4>(p, maxM, ncls, st, ws_bytes, ws_query);                    //  16 ch x 256 px
 }
 
 }  // namespace
@@ -367,8 +438,8 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
   return VFD_OK;
 }
 
-extern "C" int vfd_conv_forward(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias,
-                                void* y, float* stats, void* stream) {
+static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
+                         void* ws, size_t ws_bytes, size_t* ws_query, void* stream) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
   vfd_conv_desc dn = *d_in;
   if (dn.transposed) {
@@ -382,8 +453,10 @@ extern "C" int vfd_conv_forward(const vfd_conv_desc* d_in, const void* x, const 
   const vfd_conv_desc* d = &dn;
   int rc = vfd_conv_check_desc(d);
   if (rc != VFD_OK) return rc;
-  VFD_REQUIRE(x && packed && y, "conv: null tensor pointer");
-  VFD_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y) & 15) == 0, "conv: tensors must be 16-byte aligned");
+  if (ws_query == nullptr) {
+    VFD_REQUIRE(x && packed && y, "conv: null tensor pointer");
+    VFD_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y | (uintptr_t)ws) & 15) == 0, "conv: tensors must be 16-byte aligned");
+  }
   ConvP p;
   p.x = x; p.w = packed; p.y = y; p.bias = bias; p.stats = stats;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = cpad(d->Cin);
@@ -393,6 +466,7 @@ extern "C" int vfd_conv_forward(const vfd_conv_desc* d_in, const void* x, const 
   p.transposed = d->transposed;
   p.Kw = d->kd * d->kh * d->kw * p.Cip;
   p.act = d->act; p.slope = d->slope;
+  p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
   long long maxM;
   int ncls = 1;
   if (!d->transposed) {
@@ -403,5 +477,16 @@ extern "C" int vfd_conv_forward(const vfd_conv_desc* d_in, const void* x, const 
     maxM = (long long)d->N * qd * qh * qw;
   }
   hipStream_t st = as_stream(stream);
-  return d->dtype == VFD_BF16 ? launch<bf16_t>(p, maxM, ncls, st) : launch<float>(p, maxM, ncls, st);
+  return d->dtype == VFD_BF16 ? launch<bf16_t>(p, maxM, ncls, st, ws_bytes, ws_query) : launch<float>(p, maxM, ncls, st, ws_bytes, ws_query);
+}
+
+extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes) {
+  VFD_REQUIRE(bytes != nullptr, "conv_workspace: null result pointer");
+  float dummy;
+  return conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, want_stats ? &dummy : nullptr, nullptr, 0, bytes, nullptr);
+}
+
+extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
+                                float* stats, void* ws, size_t ws_bytes, void* stream) {
+  return conv_dispatch(d, x, packed, bias, y, stats, ws, ws_bytes, nullptr, stream);
 }

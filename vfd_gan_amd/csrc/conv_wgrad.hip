@@ -198,23 +198,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     }
 }
 
-// dw[a][b][t] = beta*dw + sum_z ws[z][a][t*Cbp + b]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B, int T, int Bp,
-                                    int nsplit, float beta) {
+// dw[a][b][t] = beta*dw + sum_z ws[z][a][t*Cbp + b].  64 elements x 4 split-lanes per workgroup: consecutive
+// threads read consecutive slab columns (coalesced), every split-lane folds a quarter of the slabs, LDS sums the
+// lanes in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B,
+                                                           int T, int Bp, int nsplit, float beta) {
   const long long total = (long long)A * T * B;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int b = (int)(idx % B);
-  const long long at = idx / B;
-  const int t = (int)(at % T);
-  const int a = (int)(at / T);
+  const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const long long idx = (long long)blockIdx.x * 64 + el;
   const size_t ncols = (size_t)T * Bp;
   const size_t slab = (size_t)A * ncols;
-  const size_t off = (size_t)a * ncols + (size_t)t * Bp + b;
   float s = 0.f;
-  for (int z = 0; z < nsplit; ++z) s += ws[z * slab + off];
-  float* dst = dw + ((size_t)a * B + b) * T + t;
-  *dst = (beta != 0.f) ? beta * (*dst) + s : s;
+  int a = 0, b = 0, t = 0;
+  if (idx < total) {
+    b = (int)(idx % B);
+    const long long at = idx / B;
+    t = (int)(at % T);
+    a = (int)(at / T);
+    const size_t off = (size_t)a * ncols + (size_t)t * Bp + b;
+    for (int z = zl; z < nsplit; z += 4) s += ws[z * slab + off];
+  }
+  __shared__ float sh[4][64];
+  sh[zl][el] = s;
+  __syncthreads();
+  if (zl == 0 && idx < total) {
+    s = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
+    float* dst = dw + ((size_t)a * B + b) * T + t;
+    *dst = (beta != 0.f) ? beta * (*dst) + s : s;
+  }
 }
 
 struct WgGeom {
@@ -249,7 +260,7 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   long long nsplit = 2048 / tiles;
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
   if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit > 1024) nsplit = 1024;
+  if (nsplit > 256) nsplit = 256;
   if (nsplit < 1) nsplit = 1;
   const size_t slab = (size_t)p.Cs * p.ncols * sizeof(float);
   while (nsplit > 1 && slab * (size_t)nsplit > ((size_t)512 << 20)) nsplit /= 2;
@@ -299,9 +310,8 @@ extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* d
   if (rc != VFD_OK) return rc;
   VFD_REQUIRE(ws && dw, "wgrad_reduce: null pointer");
   const long long total = (long long)g.A * g.T * g.B;
-  const int threads = 256;
-  const long long blocks = (total + threads - 1) / threads;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream),
+  const long long blocks = (total + 63) / 64;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta);
   VFD_CHECK_LAUNCH("wgrad_reduce");
   return VFD_OK;

@@ -195,9 +195,62 @@ def _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act=0, sl
     return d
 
 
+class KernelTimer:
+    """Optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's live
+    roofline).  ``records`` holds (kernel name, algorithmic FLOPs, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_TIMER = [None]
+
+
+def set_kernel_timer(t):
+    _TIMER[0] = t
+
+
+def _igemm_name(desc):
+    """Name of the conv_igemm instantiation vfd_conv_forward dispatches to (conv_igemm.hip: launch<T>)."""
+    t = "bf16" if desc.dtype == _lib.BF16 else "f32"
+    c = desc.Cout
+    tile = "128c_x_128p" if c > 64 else ("64c_x_256p" if c > 32 else ("32c_x_256p" if c > 16 else "16c_x_256p"))
+    return "conv_igemm<%s,%s>" % (t, tile)
+
+
+def _conv_flops(desc):
+    taps = desc.kd * desc.kh * desc.kw
+    if desc.transposed:
+        px = desc.N * desc.Di * desc.Hi * desc.Wi
+    else:
+        px = desc.N * desc.Do * desc.Ho * desc.Wo
+    return 2.0 * px * taps * desc.Cin * desc.Cout
+
+
 def _conv_launch(desc, x, packed, bias, out, stats=None):
-    check(load().vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
-                                  ptr(stats), stream()), "conv_forward")
+    timer = _TIMER[0]
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    lib = load()
+    need = ctypes.c_size_t()
+    check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
+    ws = torch.empty(need.value, dtype=torch.uint8, device=x.device) if need.value else None
+    check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
+                               ptr(stats), ptr(ws), need.value, stream()), "conv_forward")
+    if timer is not None:
+        e1.record()
+        timer.records.append((_igemm_name(desc), _conv_flops(desc), e0, e1))
 
 
 class _Conv(torch.autograd.Function):
@@ -254,8 +307,15 @@ class _Conv(torch.autograd.Function):
             nbytes = ctypes.c_size_t()
             check(lib.vfd_wgrad_workspace(ctypes.byref(desc), ctypes.byref(nsplit), ctypes.byref(nbytes)), "wgrad_workspace")
             ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+            timer = _TIMER[0]
+            if timer is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             check(lib.vfd_conv_wgrad(ctypes.byref(desc), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, stream()),
                   "conv_wgrad")
+            if timer is not None:
+                e1.record()
+                timer.records.append(("conv_wgrad<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"), _conv_flops(desc), e0, e1))
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
         if ctx.has_bias and ctx.needs_input_grad[2]:
