@@ -57,6 +57,13 @@ int vfd_ncs_to_nsc(int dtype, const float* src, void* dst, int64_t N, int C, int
 /* src dtype [N][S][Cp] -> dst float32 [N][C][S] (pad channels dropped).                          */
 int vfd_nsc_to_ncs(int dtype, const void* src, float* dst, int64_t N, int C, int64_t S, void* stream);
 
+/* The reference's reshapes between a feature vector and a block, in the compute dtype:
+ *   x.view(N, C, D, H, W) of an (N, C*S) vector (models/anogan.py:76):  src [N][1][C*S] -> dst [N][S][CPAD(C)]
+ *   x.view(N, -1) of a block (models/anogan.py:115):                    src [N][S][CPAD(C)] -> dst [N][1][C*S]
+ * C*S must be a multiple of 8 (so the flat vector carries no channel padding).                     */
+int vfd_unflatten(int dtype, const void* src, void* dst, int64_t N, int C, int64_t S, void* stream);
+int vfd_flatten(int dtype, const void* src, void* dst, int64_t N, int C, int64_t S, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolution family: nn.Conv3d / nn.ConvTranspose3d / nn.Conv2d / nn.ConvTranspose2d / nn.Linear
  *   models/anogan.py:44,51-52,56-57,64-65,69-70,85,88-89,96-97,101,108

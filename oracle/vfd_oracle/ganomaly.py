@@ -123,11 +123,11 @@ def make_optimizers(netg, netd, opt):
             torch.optim.Adam(netd.parameters(), lr=opt.lr, betas=(opt.beta1, 0.999)))
 
 
-def step(netg, netd, opt_g, opt_d, x, opt, nets=(NetG, NetD)):
+def step(netg, netd, opt_g, opt_d, x, opt, l2=l2_loss):
     """One optimize_params() of reference models/ganomaly.py:502-519 on frames `x` (N,3,S,S).
     Works on any module pair with the NetG / NetD call signatures (the reference's own classes in the fixture
     generator, this file's classes in the tests).  Returns the loss scalars."""
-    l_adv, l_con, l_enc, l_bce = l2_loss, nn.L1Loss(), l2_loss, nn.BCELoss()      # :437-440
+    l_adv, l_con, l_enc, l_bce = l2, nn.L1Loss(), l2, nn.BCELoss()                # :437-440
     real_label = torch.ones(x.shape[0])
     fake_label = torch.zeros(x.shape[0])
     fake, latent_i, latent_o = netg(x)                                           # forward_g :459-462

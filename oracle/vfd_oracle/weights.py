@@ -47,6 +47,7 @@ def summarize(t):
     """Compact signature of a tensor for fixtures of large outputs: shape, sum, abs-sum, 16 strided samples."""
     t = t.detach().double().reshape(-1)
     n = t.numel()
-    idx = torch.linspace(0, n - 1, steps=min(16, n)).long()
+    k = min(16, n)
+    idx = (torch.arange(k, dtype=torch.int64) * (n - 1)) // max(k - 1, 1)
     return {"n": n, "sum": float(t.sum()), "abssum": float(t.abs().sum()), "sqsum": float((t * t).sum()),
             "samples": t[idx].tolist(), "idx": idx.tolist()}

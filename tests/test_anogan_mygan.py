@@ -1,0 +1,220 @@
+"""GPU parity of the anogan and mygan nets / training steps: against the CPU oracle on small generalised
+geometries (f32 tight, bf16 stated tolerance) and against the reference's golden vectors at the reference's own
+16x128x128 geometry (SURVEY.md sections 0, 8c)."""
+import types
+
+import pytest
+import torch
+
+from golden_util import check_errs, check_summary, load_golden
+from util import relerr, relrms
+
+pytestmark = pytest.mark.gpu
+JS, NPZ = load_golden()
+
+
+def _args(tmp, model, B, T, S, **kw):
+    d = dict(batchsize=B, nfr=T, isize=S, ich=3, lr=2e-5, beta1=0.5, w_adv=1, w_con=10, pos_weight=2, freq=10 ** 9, ep=1,
+             model=model, result_root=str(tmp), gpu=[0], ae=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _p0(m):
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+
+
+def _mask_provider():
+    from vfd_oracle.weights import seeded_tensor
+    return lambda shape, p, idx: seeded_tensor(tuple(shape), 1000 + idx, 0.0, 1.0) >= p
+
+
+def _compare_state(model_sd, ref_sd, f32, lr, steps, skip=()):
+    for (k, v), (_, r) in zip(model_sd.items(), ref_sd.items()):
+        if any(s in k for s in skip):
+            continue
+        if "num_batches_tracked" in k:
+            assert int(v) == int(r), k
+        elif "running_" in k:
+            assert relerr(v, r) < (1e-3 if f32 else 6e-2), (k, relerr(v, r))
+        else:
+            d = (v.detach().cpu().double() - r.detach().double()).abs()
+            assert float(d.mean()) <= (0.1 if f32 else 0.6) * lr * steps, (k, float(d.mean()))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_anogan_step_small(dt, dev, tmp_path):
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import anogan as HA
+    from vfd_oracle import anogan as OA
+    from vfd_oracle.weights import fill_module, seeded_normal, seeded_tensor
+    F.set_compute_dtype(dt)
+    B, T, S = 3, 8, 32
+    og, od = fill_module(OA.NetG(T, S), 1).train(), fill_module(OA.NetD(T, S), 2).train()
+    _p0(og)
+    model = HA.AnoGAN(_args(tmp_path, "anogan", B, T, S), None)
+    model.netg.load_state_dict(og.state_dict())
+    model.netd.load_state_dict(od.state_dict())
+    _p0(model.netg)
+    F.invalidate_weight_cache()
+    g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
+    f32 = dt == torch.float32
+    for it in range(2):
+        z, real = seeded_normal((B, 100), 10 + it), seeded_tensor((B, 3, T, S, S), 20 + it)
+        ref, fake_ref = OA.step(og, od, g_opt, d_opt, real, z)
+        model.set_input((real, real, real[:, :1], torch.ones(B, T)))
+        model.z = z.to(dev)
+        model.optimize_params()
+        got = model.errors()
+        for k, v in ref.items():
+            g = got["%s/%s/train" % (k[4], k)]
+            assert abs(g - v) <= (2e-4 if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+        # step 0 compares the same weights; later steps also carry Adam's sign-amplified rounding noise of the
+        # previous update (every weight moves ~lr whatever its gradient's size), hence the RMS metric there
+        if f32 and it == 0:
+            assert relerr(model.gen_fake.to_torch(), fake_ref) < 5e-4, it
+        else:
+            assert relrms(model.gen_fake.to_torch(), fake_ref) < (5e-3 if f32 else 4e-2), (it, relrms(model.gen_fake.to_torch(), fake_ref))
+    # A bias that feeds straight into a training-mode BatchNorm has an exactly-zero true gradient (the batch mean
+    # absorbs it); what each implementation computes there is rounding noise, which Adam turns into +-lr moves.
+    # The reference's own values for those entries are noise, so they are not compared.
+    _compare_state(model.netd.state_dict(), od.state_dict(), f32, 2e-5, 2,
+                   skip=("layer1.0.bias", "layer1.4.bias", "layer2.1.bias", "layer2.5.bias"))
+    _compare_state(model.netg.state_dict(), og.state_dict(), f32, 1e-4, 2,
+                   skip=("layer1.0.bias", "layer2.2.bias", "layer2.7.bias", "layer3.2.bias"))
+
+
+def test_anogan_reference_geometry_golden(dev, tmp_path):
+    """16x128x128, B=2, float32: HIP step against the vectors the reference's own NetG / NetD produced."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import anogan as HA
+    from vfd_oracle.weights import fill_module, seeded_normal, seeded_tensor
+    F.set_compute_dtype(torch.float32)
+    R = JS["anogan"]
+    model = HA.AnoGAN(_args(tmp_path, "anogan", 2, 16, 128), None)
+    assert list(model.netg.state_dict().keys()) == R["keys_g"] and list(model.netd.state_dict().keys()) == R["keys_d"]
+    fill_module(model.netg, R["seeds"]["g"])
+    fill_module(model.netd, R["seeds"]["d"])
+    F.invalidate_weight_cache()
+    z, real = seeded_normal((2, 100), R["seeds"]["z"]), seeded_tensor((2, 3, 16, 128, 128), R["seeds"]["real"])
+    # forward with the imposed dropout masks of the fixture
+    F.set_dropout_mask_provider(_mask_provider())
+    try:
+        out = model.netg(F.to_cl(z.to(dev)))
+    finally:
+        F.set_dropout_mask_provider(None)
+    check_summary(out.to_torch(), R["fwd_masked"]["fake"], 5e-4, "masked fake")
+    fill_module(model.netg, R["seeds"]["g"])     # running stats were advanced by the forward above
+    F.invalidate_weight_cache()
+    _p0(model.netg)
+    model.set_input((real, real, real[:, :1], torch.ones(2, 16)))
+    model.z = z.to(dev)
+    model.optimize_params()
+    got = model.errors()
+    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 5e-4)
+    check_summary(model.gen_fake.to_torch(), R["step_p0"]["fake"], 1e-3, "fake")
+    for k, ref in R["after1"]["d"].items():
+        if "running" in k:
+            check_summary(model.netd.state_dict()[k], ref, 2e-3, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_mygan_step_small(dt, dev, tmp_path):
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import mygannet as HM
+    from vfd_oracle import mygannet as OM
+    from vfd_oracle.weights import fill_module, seeded_tensor
+    F.set_compute_dtype(dt)
+    B, T, S = 2, 16, 64
+    og, od = fill_module(OM.NetG(), 3).train(), fill_module(OM.NetD(OM.make_args(T, S)), 4).train()
+    _p0(og)
+    model = HM.MyGAN(_args(tmp_path, "mygan", B, T, S), None)
+    model.netg.load_state_dict(og.state_dict())
+    model.netd.load_state_dict(od.state_dict())
+    _p0(model.netg)
+    F.invalidate_weight_cache()
+    opt_g, opt_d = OM.make_optimizers(og, od)
+    f32 = dt == torch.float32
+    for it in range(2):
+        inp = seeded_tensor((B, 3, T, S, S), 30 + it)
+        gt = (seeded_tensor((B, 1, T, S, S), 40 + it, 0.0, 1.0) > 0.97).float()
+        gf, pf = seeded_tensor((B, 3, T, S, S), 50 + it), seeded_tensor((B, 3, T, S, S), 60 + it)
+        ref, pred_ref = OM.step(og, od, opt_g, opt_d, inp, gt, gf, pf)
+        model.set_input((inp, inp, gt, torch.ones(B, T)), gt_flow=gf, pre_flow=pf)
+        model.optimize_params()
+        got = model.errors()
+        for k, v in ref.items():
+            g = got["%s/%s/train" % (k[4], k)]
+            assert abs(g - v) <= (2e-4 if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+        if f32 and it == 0:
+            assert relerr(model.predict.to_torch(), pred_ref) < 5e-4, it
+        else:
+            assert relrms(model.predict.to_torch(), pred_ref) < (5e-3 if f32 else 4e-2), (it, relrms(model.predict.to_torch(), pred_ref))
+    # (2+1)D conv biases all feed a BatchNorm: zero true gradient, see test_anogan_step_small
+    _compare_state(model.netg.state_dict(), og.state_dict(), f32, 2e-5, 2, skip=("_conv.bias",))
+    _compare_state(model.netd.state_dict(), od.state_dict(), f32, 2e-5, 2, skip=("_conv.bias",))
+
+
+def test_mygan_reference_geometry_golden(dev, tmp_path):
+    """16x128x128, B=2, float32: HIP nets / step against the vectors of the reference's own NetG / NetD / losses."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import mygannet as HM
+    from vfd_oracle.weights import fill_module, seeded_tensor
+    F.set_compute_dtype(torch.float32)
+    R = JS["mygan"]
+    s = R["seeds"]
+    model = HM.MyGAN(_args(tmp_path, "mygan", 2, 16, 128), None)
+    assert list(model.netg.state_dict().keys()) == R["keys_g"] and list(model.netd.state_dict().keys()) == R["keys_d"]
+    fill_module(model.netg, s["g"])
+    fill_module(model.netd, s["d"])
+    F.invalidate_weight_cache()
+    inp = seeded_tensor((2, 3, 16, 128, 128), s["inp"])
+    gt = (seeded_tensor((2, 1, 16, 128, 128), s["gt"], 0.0, 1.0) > 0.97).float()
+    gf, pf = seeded_tensor((2, 3, 16, 128, 128), s["gt_flow"]), seeded_tensor((2, 3, 16, 128, 128), s["pre_flow"])
+    F.set_dropout_mask_provider(_mask_provider())
+    try:
+        out = model.netg(F.to_cl(inp[:1].to(dev)))
+    finally:
+        F.set_dropout_mask_provider(None)
+    check_summary(out.to_torch(), R["fwd_masked"]["predict"], 5e-4, "masked predict")
+    # the U-Net is size-agnostic: 16x112x112 matches the reference too
+    fill_module(model.netg, s["g"])
+    F.invalidate_weight_cache()
+    _p0(model.netg)
+    out112 = model.netg(F.to_cl(seeded_tensor((1, 3, 16, 112, 112), 67).to(dev)))
+    check_summary(out112.to_torch(), R["fwd_112"]["predict"], 5e-4, "predict@112")
+    fill_module(model.netg, s["g"])
+    F.invalidate_weight_cache()
+    model.set_input((inp, inp, gt, torch.ones(2, 16)), gt_flow=gf, pre_flow=pf)
+    model.optimize_params()
+    got = model.errors()
+    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 5e-4)
+    check_summary(model.predict.to_torch(), R["step_p0"]["predict"], 1e-3, "predict")
+
+
+def test_ganomaly_golden(dev, tmp_path):
+    """ganomaly at a power-of-two size against the reference's own Encoder/Decoder/NetG/NetD vectors (3 steps)."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import ganomaly as HG
+    from vfd_oracle.weights import fill_module, seeded_tensor
+    F.set_compute_dtype(torch.float32)
+    R = JS["ganomaly"]
+    cfg = R["cfg"]
+    args = _args(tmp_path, "ganomaly", 2, 4, cfg["isize"], lr=2e-4, w_con=50)
+    model = HG.Ganomaly(args, None, opt=HG.make_opt(isize=cfg["isize"], ngf=cfg["ngf"]))
+    assert list(model.netg.state_dict().keys()) == R["keys_g"] and list(model.netd.state_dict().keys()) == R["keys_d"]
+    fill_module(model.netg, R["seeds"]["g"])
+    fill_module(model.netd, R["seeds"]["d"])
+    F.invalidate_weight_cache()
+    for it in range(3):
+        x = seeded_tensor((8, 3, 32, 32), 30 + it)
+        clip = x.view(2, 4, 3, 32, 32).permute(0, 2, 1, 3, 4).contiguous()      # 8 frames = 2 clips x 4 frames
+        model.set_input((clip, clip, clip[:, :1], torch.ones(2, 4)))
+        model.optimize_params(check_collapse=False)
+        got = model.errors()
+        check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["steps"][it]["errs"]}, R["steps"][it]["errs"], 2e-4, "step %d" % it)
+        check_summary(model.fake.to_torch(), R["steps"][it]["fake"], 1e-3, "fake %d" % it)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "vfd_last_error": (ctypes.c_char_p, []),
     "vfd_ncs_to_nsc": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_nsc_to_ncs": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
+    "vfd_unflatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
+    "vfd_flatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_pack_filter": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vfd_conv_workspace": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_sz)]),

@@ -54,6 +54,45 @@ __global__ void nsc_to_ncs_kernel(const T* __restrict__ src, float* __restrict__
   }
 }
 
+// [N][C][S] <-> [N][S][Cp] in the SAME dtype: the `x.view(N, C, D, H, W)` / `x.view(N, -1)` reshapes of the
+// reference (models/anogan.py:76,115) expressed on channels-last blocks.
+template <typename T>
+__global__ void tt_ncs_to_nsc_kernel(const T* __restrict__ src, T* __restrict__ dst, long long N, int C, long long S) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = N * S * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % S;
+    const long long ng = i / S;
+    const int g = (int)(ng % GR);
+    const long long n = ng / GR;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      v[k] = (c < C) ? Elem<T>::ld(src + (n * C + c) * S + s) : 0.f;
+    }
+    store8(dst + (n * S + s) * Cp + g * 8, v);
+  }
+}
+template <typename T>
+__global__ void tt_nsc_to_ncs_kernel(const T* __restrict__ src, T* __restrict__ dst, long long N, int C, long long S) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const long long total = N * S * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long s = i % S;
+    const long long ng = i / S;
+    const int g = (int)(ng % GR);
+    const long long n = ng / GR;
+    float v[8];
+    load8(src + (n * S + s) * Cp + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      if (c < C) Elem<T>::st(dst + (n * C + c) * S + s, v[k]);
+    }
+  }
+}
+
 // ---- filter packing -----------------------------------------------------------------------------------
 // w f32 [A][B][T] -> packed T [R][T][Ccp] ; transpose_ab=0: R=A,Cc=B ; 1: R=B,Cc=A.  One thread per element
 // of the packed block (pad channels written as zero).
@@ -311,6 +350,30 @@ extern "C" int vfd_nsc_to_ncs(int dtype, const void* src, float* dst, int64_t N,
   else
     hipLaunchKernelGGL(nsc_to_ncs_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, dst, (long long)N, C, (long long)S);
   VFD_CHECK_LAUNCH("nsc_to_ncs");
+  return VFD_OK;
+}
+
+extern "C" int vfd_unflatten(int dtype, const void* src, void* dst, int64_t N, int C, int64_t S, void* stream) {
+  CHECK_DTYPE(dtype, "unflatten");
+  VFD_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ((C * S) & 7) == 0, "unflatten: bad arguments (C*S must be a multiple of 8)");
+  const long long total = (long long)N * S * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(tt_ncs_to_nsc_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)src, (bf16_t*)dst, (long long)N, C, (long long)S);
+  else
+    hipLaunchKernelGGL(tt_ncs_to_nsc_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, (float*)dst, (long long)N, C, (long long)S);
+  VFD_CHECK_LAUNCH("unflatten");
+  return VFD_OK;
+}
+
+extern "C" int vfd_flatten(int dtype, const void* src, void* dst, int64_t N, int C, int64_t S, void* stream) {
+  CHECK_DTYPE(dtype, "flatten");
+  VFD_REQUIRE(src && dst && N > 0 && C > 0 && S > 0 && ((C * S) & 7) == 0, "flatten: bad arguments (C*S must be a multiple of 8)");
+  const long long total = (long long)N * S * (cpad(C) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(tt_nsc_to_ncs_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)src, (bf16_t*)dst, (long long)N, C, (long long)S);
+  else
+    hipLaunchKernelGGL(tt_nsc_to_ncs_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)src, (float*)dst, (long long)N, C, (long long)S);
+  VFD_CHECK_LAUNCH("flatten");
   return VFD_OK;
 }
 

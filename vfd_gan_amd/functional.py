@@ -139,6 +139,53 @@ def from_cl(x):
     return _FromCl.apply(x.t, x.C, x.nsp)
 
 
+class _Reshape(torch.autograd.Function):
+    """unflatten: (N, C*S) feature vector -> (N, C, D, H, W) block;  flatten: the inverse (reference order)."""
+
+    @staticmethod
+    def forward(ctx, t, C, dhw, unflatten):
+        t = t.contiguous()
+        N = t.shape[0]
+        S = dhw[0] * dhw[1] * dhw[2]
+        lib = load()
+        if unflatten:
+            out = torch.empty((N,) + tuple(dhw) + (cpad(C),), dtype=t.dtype, device=t.device)
+            check(lib.vfd_unflatten(dtype_code(t.dtype), t.data_ptr(), out.data_ptr(), N, C, S, stream()), "unflatten")
+        else:
+            out = torch.empty((N, 1, 1, 1, C * S), dtype=t.dtype, device=t.device)
+            check(lib.vfd_flatten(dtype_code(t.dtype), t.data_ptr(), out.data_ptr(), N, C, S, stream()), "flatten")
+        ctx.meta = (N, C, S, tuple(t.shape), unflatten)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, S, shape, unflatten = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(shape, dtype=g.dtype, device=g.device)
+        lib = load()
+        if unflatten:
+            check(lib.vfd_flatten(dtype_code(g.dtype), g.data_ptr(), out.data_ptr(), N, C, S, stream()), "flatten")
+        else:
+            check(lib.vfd_unflatten(dtype_code(g.dtype), g.data_ptr(), out.data_ptr(), N, C, S, stream()), "unflatten")
+        return out, None, None, None
+
+
+def unflatten(x, shape):
+    """``x.view(N, C, D, H, W)`` of an (N, C*D*H*W) ClTensor (reference models/anogan.py:76)."""
+    C, dhw = shape[0], tuple(shape[1:])
+    if x.nsp != 0 or x.C != C * dhw[0] * dhw[1] * dhw[2] or x.C % 8:
+        raise RuntimeError("unflatten: cannot view %s as %s" % (x.shape, shape))
+    return ClTensor(_Reshape.apply(x.t, C, dhw, True), C, 3)
+
+
+def flatten(x):
+    """``x.view(N, -1)`` of an (N, C, D, H, W) ClTensor, in the reference's (C, D, H, W) feature order."""
+    n, d, h, w, _ = x.t.shape
+    if (x.C * d * h * w) % 8:
+        raise RuntimeError("flatten: %s has a feature count that is not a multiple of 8" % (x.shape,))
+    return ClTensor(_Reshape.apply(x.t, x.C, (d, h, w), False), x.C * d * h * w, 0)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # convolution family
 # ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,165 @@
+"""AnoGAN nets and training step on HIP kernels, behind the surface of the reference's models/anogan.py
+(NetG :39-79, NetD :81-119, AnoGAN :121-143, optimize_params :229-250).
+
+Generalisation (SURVEY.md sections 0, 8d): the reference hard-wires 16x128x128; here the generator's seed volume is
+(512, nfr/8, isize/8, isize/8) and the discriminator's Linear has 256*(nfr/8)*(isize/8)^2 inputs, which at the
+defaults (nfr=16, isize=128) are the reference's modules exactly (same state_dict keys and shapes).
+"""
+import torch
+import torch.nn as tnn
+
+from .. import dist as vdist
+from .. import functional as F
+from .. import nn as hnn
+from .. import optim as hoptim
+from ..functional import ClTensor
+from ..lib.train_gan import GANBaseModel
+from ..lib.utils import weights_init
+
+
+class NetG(tnn.Module):
+    def __init__(self, nfr=16, isize=128):
+        super(NetG, self).__init__()
+        self.seed_shape = (512, nfr // 8, isize // 8, isize // 8)
+        feat = 512 * (nfr // 8) * (isize // 8) * (isize // 8)
+        self.layer1 = hnn.Sequential(
+            hnn.Linear(100, feat),
+            hnn.BatchNorm1d(feat),
+            hnn.ReLU(),
+        )
+        self.layer2 = hnn.Sequential(
+            hnn.Dropout(p=0.25),
+            hnn.ConvTranspose3d(512, 256, 3, 2, 1, 1),
+            hnn.Conv3d(256, 256, 3, 1, 1),
+            hnn.BatchNorm3d(256),
+            hnn.LeakyReLU(),
+            hnn.Dropout(p=0.25),
+            hnn.ConvTranspose3d(256, 128, 3, 2, 1, 1),
+            hnn.Conv3d(128, 128, 3, 1, 1),
+            hnn.BatchNorm3d(128),
+            hnn.LeakyReLU()
+        )
+        self.layer3 = hnn.Sequential(
+            hnn.Dropout(p=0.25),
+            hnn.ConvTranspose3d(128, 64, 3, 1, 1),
+            hnn.Conv3d(64, 64, 3, 1, 1),
+            hnn.BatchNorm3d(64),
+            hnn.LeakyReLU(),
+            hnn.Dropout(p=0.25),
+            hnn.ConvTranspose3d(64, 3, 3, 2, 1, 1),
+            hnn.Conv3d(3, 3, 3, 1, 1),
+            hnn.Sigmoid()
+        )
+
+    def forward(self, z):
+        plain = not isinstance(z, ClTensor)
+        x = self.layer1(F.to_cl(z) if plain else z)
+        x = F.unflatten(x, self.seed_shape)          # x.view(N, 512, 2, 16, 16) of the reference (:76)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        return x.to_torch() if plain else x
+
+
+class NetD(tnn.Module):
+    def __init__(self, nfr=16, isize=128):
+        super(NetD, self).__init__()
+        self.layer1 = hnn.Sequential(
+            hnn.Conv3d(3, 32, 3, stride=1, padding=1),
+            hnn.BatchNorm3d(32),
+            hnn.LeakyReLU(),
+            hnn.Conv3d(32, 64, 3, stride=1, padding=1),
+            hnn.Conv3d(64, 64, 3, stride=1, padding=1),
+            hnn.BatchNorm3d(64),
+            hnn.LeakyReLU(64),     # slope 64, exactly as the reference writes it (:91)
+            hnn.AvgPool3d(2)
+        )
+        self.layer2 = hnn.Sequential(
+            hnn.Conv3d(64, 128, 3, stride=1, padding=1),
+            hnn.Conv3d(128, 128, 3, stride=1, padding=1),
+            hnn.BatchNorm3d(128),
+            hnn.LeakyReLU(),
+            hnn.AvgPool3d(2),
+            hnn.Conv3d(128, 256, 3, stride=1, padding=1),
+            hnn.BatchNorm3d(256),
+            hnn.LeakyReLU(),
+            hnn.AvgPool3d(2)
+        )
+        self.fc = hnn.Sequential(
+            hnn.Linear(256 * (nfr // 8) * (isize // 8) * (isize // 8), 1),
+            hnn.Sigmoid()
+        )
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        x = self.layer1(F.to_cl(x) if plain else x)
+        x = self.layer2(x)
+        feature = x                      # the reference returns x.view(N, -1); the Linear below takes the block
+        out = self.fc(x)                 # Linear over the flattened (C,D,H,W) features + Sigmoid, one kernel
+        if plain:
+            return out.to_torch(), F.flatten(feature).to_torch()
+        return out, feature
+
+
+class AnoGAN(GANBaseModel):
+    def __init__(self, args, dataloader):
+        super(AnoGAN, self).__init__(args, dataloader)
+        self.netg = NetG(args.nfr, args.isize).to(self.device)
+        self.netd = NetD(args.nfr, args.isize).to(self.device)
+        self.netg.apply(weights_init)
+        self.netd.apply(weights_init)
+        vdist.broadcast_module(self.netg)
+        vdist.broadcast_module(self.netd)
+        self.netg.train()
+        self.netd.train()
+
+        self.loss = F.bce_loss
+        # reference :139-140 — the generator runs at 5*lr and betas are hard-coded (args.beta1 is ignored)
+        self.g_opt = hoptim.Adam(self.netg.parameters(), lr=5 * args.lr, betas=(0.5, 0.999))
+        self.d_opt = hoptim.Adam(self.netd.parameters(), lr=args.lr, betas=(0.5, 0.999))
+        self.reducer_g = vdist.GradReducer.for_optimizer(self.g_opt)
+        self.reducer_d = vdist.GradReducer.for_optimizer(self.d_opt)
+        self.ones_label, self.zeros_label = 1.0, 0.0
+        self._zgen = torch.Generator(device=self.device)
+        self._zgen.manual_seed(4321 + 7919 * self.rank)     # per-rank noise streams
+        self.z = None                                       # tests may impose the noise
+
+    def set_input(self, data):
+        super(AnoGAN, self).set_input(data)
+        self.real_cl = F.to_cl(self.real)
+
+    def optimize_params(self):
+        # NetD  (reference :231-243)
+        self.d_opt.zero_grad()
+        dis_real = self.netd(self.real_cl)[0]
+        dis_loss_real = self.loss(dis_real, self.ones_label)
+        dis_loss_real.backward()
+
+        z = self.z if self.z is not None else torch.randn(self.args.batchsize, 100, device=self.device, generator=self._zgen)
+        gen_fake = self.netg(F.to_cl(z))
+        dis_fake = self.netd(gen_fake.detach())[0]
+        dis_loss_fake = self.loss(dis_fake, self.zeros_label)
+        dis_loss_fake.backward()
+        dis_loss = dis_loss_real + dis_loss_fake
+        self.reducer_d.finish()
+        self.d_opt.step()
+
+        # NetG  (reference :246-250).  netD's own gradients from this backward are never used by the reference
+        # (the next step starts with netd.zero_grad()), so netD is frozen here and only the data gradient flows.
+        self.g_opt.zero_grad()
+        for p in self.netd.parameters():
+            p.requires_grad_(False)
+        self.reducer_d.enabled = False
+        try:
+            dis_fake = self.netd(gen_fake)[0]
+            gen_loss = self.loss(dis_fake, self.ones_label)
+            gen_loss.backward()
+        finally:
+            for p in self.netd.parameters():
+                p.requires_grad_(True)
+            self.reducer_d.enabled = True
+        self.reducer_g.finish()
+        self.g_opt.step()
+
+        self.gen_fake = gen_fake.detach()
+        self.errors_dict.update({'d/err_d/train': dis_loss, 'g/err_g/train': gen_loss,
+                                 'd/err_d_real/train': dis_loss_real, 'd/err_d_fake/train': dis_loss_fake})

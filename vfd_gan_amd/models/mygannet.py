@@ -1,0 +1,267 @@
+"""MyGAN ((2+1)D U-Net generator + spatial / temporal dual discriminator) on HIP kernels, behind the surface of the
+reference's models/mygannet.py (NetgConv :13-28, NetG :31-101, NetdConv :104-116, SDisc :119-162, TDisc :164-196,
+NetD :200-213, MyGAN :216-367).
+
+Generalisation: SDisc.linear / TDisc.linear in-features follow (nfr, isize) instead of the reference's hard-wired
+nfr=16, isize=128 (:134, :176); at those defaults they are 4096 and 256 as in the reference.
+Optical flow (lib/utils.py:94-129, CPU Farneback through cv2) is outside the hot path: the temporal discriminator's
+input streams are inputs of the step (`self.gt_flow`, `self.pre_flow`; synthetic stand-ins by default).
+"""
+import types
+
+import torch
+import torch.nn as tnn
+
+from .. import _lib
+from .. import dist as vdist
+from .. import functional as F
+from .. import nn as hnn
+from .. import optim as hoptim
+from ..functional import ClTensor
+from ..lib.data import synthetic_flow
+from ..lib.train_gan import GANBaseModel
+from ..lib.utils import weights_init
+from .spatiotempconv import SpatioTemporalConv
+
+
+def _conv_bn_act(block, x, slope):
+    """SpatioTemporalConv -> BatchNorm3d -> LeakyReLU(slope) with the BatchNorm statistics taken from the temporal
+    conv's epilogue (bf16) and normalise+activate in one pass."""
+    if block.bn.training and hnn.use_epilogue_stats(x):
+        sums = torch.zeros(2 * F.cpad(block.bn.num_features), dtype=torch.float32, device=x.t.device)
+        x = block.conv(x, stats=sums)
+        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=sums)
+    x = block.conv(x)
+    return block.bn(x, act=_lib.ACT_LRELU, slope=slope)
+
+
+class NetgConv(tnn.Module):
+    def __init__(self, in_fi, out_fi, kernel_size=3):
+        super(NetgConv, self).__init__()
+        padding = kernel_size // 2
+        self.conv = SpatioTemporalConv(in_fi, out_fi, kernel_size, padding=padding)
+        self.bn = hnn.BatchNorm3d(out_fi)
+        self.lrelu = hnn.LeakyReLU(0.2, inplace=True)
+
+    def forward(self, x):
+        return _conv_bn_act(self, x, self.lrelu.negative_slope)
+
+
+class NetG(tnn.Module):
+    def __init__(self, nc=3, ngf=32):
+        super(NetG, self).__init__()
+        self.dconv1 = NetgConv(nc, ngf)
+        self.dconv2 = NetgConv(ngf, ngf * 2)
+        self.dconv3 = NetgConv(ngf * 2, ngf * 4)
+        self.dconv4 = NetgConv(ngf * 4, ngf * 8)
+        self.dconv5 = NetgConv(ngf * 8, ngf * 16)
+
+        self.avgpool = hnn.AvgPool3d(2)
+
+        self.uconv5 = NetgConv(ngf * 16, ngf * 8)
+        self.uconv4 = NetgConv(ngf * 8 + ngf * 8, ngf * 8)
+        self.uconv3 = NetgConv(ngf * 8 + ngf * 4, ngf * 4)
+        self.uconv2 = NetgConv(ngf * 4 + ngf * 2, ngf * 2)
+        self.uconv1 = NetgConv(ngf * 2 + ngf, ngf)
+
+        self.dropout = hnn.Dropout(p=0.25)
+        self.upsamp = hnn.Upsample(scale_factor=2, mode='trilinear', align_corners=True)
+
+        self.conv_last = hnn.Conv3d(ngf, 1, 3, stride=1, padding=1, bias=False)
+        self.sigmoid = hnn.Sigmoid()
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        if plain:
+            x = F.to_cl(x)
+        dconv1 = self.dconv1(x)
+        dconv2 = self.dconv2(self.avgpool(dconv1))
+        dconv3 = self.dconv3(self.avgpool(dconv2))
+        dconv4 = self.dconv4(self.avgpool(dconv3))
+        latent_i = self.dconv5(self.avgpool(dconv4))
+
+        x = self.upsamp(self.dropout(self.uconv5(latent_i)))
+        x = self.upsamp(self.dropout(self.uconv4(F.cat_channels(x, dconv4))))
+        x = self.upsamp(self.dropout(self.uconv3(F.cat_channels(x, dconv3))))
+        x = self.upsamp(self.dropout(self.uconv2(F.cat_channels(x, dconv2))))
+        x = self.uconv1(F.cat_channels(x, dconv1))
+        predict = self.conv_last(x, act=_lib.ACT_SIGMOID)      # conv_last + sigmoid in one kernel
+        return predict.to_torch() if plain else predict
+
+
+class NetdConv(tnn.Module):
+    def __init__(self, in_fi, out_fi, kernel_size=None, padding=None):
+        super(NetdConv, self).__init__()
+        self.conv = SpatioTemporalConv(in_fi, out_fi, kernel_size, padding=padding)
+        self.bn = hnn.BatchNorm3d(out_fi)
+        self.lrelu = hnn.LeakyReLU()
+
+    def forward(self, x):
+        return _conv_bn_act(self, x, self.lrelu.negative_slope)
+
+
+class SDisc(tnn.Module):
+    def __init__(self, nc, nfr, ndf=32, kernel=None, padding=None, isize=128):
+        super(SDisc, self).__init__()
+        netdconv = lambda in_fi, out_fi: NetdConv(in_fi, out_fi, kernel_size=kernel, padding=padding)  # noqa: E731
+        self.dconv1 = netdconv(nc, ndf)
+        self.dconv2 = netdconv(ndf, ndf * 2)
+        self.dconv3 = netdconv(ndf * 2, ndf * 4)
+        self.dconv4 = netdconv(ndf * 4, ndf * 8)
+        self.dconv5 = netdconv(ndf * 8, ndf * 16)
+        self.dconv6 = netdconv(ndf * 16, ndf * 32)
+
+        self.avgpool = hnn.AvgPool3d((1, 2, 2))
+        self.gpool = hnn.AvgPool3d((nfr, 1, 1), stride=1)
+        self.linear = hnn.Linear(ndf * 32 * (isize // 64) * (isize // 64), 1)
+        self.sigmoid = hnn.Sigmoid()
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        if plain:
+            x = F.to_cl(x)
+        for conv in (self.dconv1, self.dconv2, self.dconv3, self.dconv4, self.dconv5, self.dconv6):
+            x = self.avgpool(conv(x))
+        features = x
+        x = self.gpool(features)
+        classifier = self.linear(x, act=_lib.ACT_SIGMOID)     # Linear over the flattened block + Sigmoid
+        if plain:
+            return classifier.to_torch().squeeze(1), features.to_torch()
+        return classifier, features
+
+
+class TDisc(tnn.Module):
+    def __init__(self, nc, isize, ndf=32, kernel=None, padding=None, nfr=16):
+        super(TDisc, self).__init__()
+        netdconv = lambda in_fi, out_fi: NetdConv(in_fi, out_fi, kernel_size=kernel, padding=padding)  # noqa: E731
+        self.dconv1 = netdconv(nc, ndf)
+        self.dconv2 = netdconv(ndf, ndf * 2)
+        self.dconv3 = netdconv(ndf * 2, ndf * 4)
+
+        self.avgpool = hnn.AvgPool3d((2, 1, 1))
+        self.gpool = hnn.AvgPool3d((1, isize, isize), stride=1)
+        self.linear = hnn.Linear(ndf * 4 * (nfr // 8), 1)
+        self.sigmoid = hnn.Sigmoid()
+
+    def forward(self, x):
+        plain = not isinstance(x, ClTensor)
+        if plain:
+            x = F.to_cl(x)
+        for conv in (self.dconv1, self.dconv2, self.dconv3):
+            x = self.avgpool(conv(x))
+        features = x
+        x = self.gpool(features)
+        classifier = self.linear(x, act=_lib.ACT_SIGMOID)
+        if plain:
+            return classifier.to_torch().squeeze(1), features.to_torch()
+        return classifier, features
+
+
+class NetD(tnn.Module):
+    def __init__(self, args):
+        super(NetD, self).__init__()
+        self.spatdisc = SDisc(3, args.nfr, kernel=(1, 3, 3), padding=(0, 1, 1), isize=args.isize)
+        self.tempdisc = TDisc(3, args.isize, kernel=(3, 1, 1), padding=(1, 0, 0), nfr=args.nfr)
+
+    def forward(self, x, y):
+        s_cls, s_feat = self.spatdisc(x)
+        t_cls, t_feat = self.tempdisc(y)
+        return s_cls, s_feat, t_cls, t_feat
+
+
+class MyGAN(GANBaseModel):
+    def __init__(self, args, dataloader):
+        super(MyGAN, self).__init__(args, dataloader)
+        if getattr(args, "ae", False):
+            raise NotImplementedError("--ae (AutoEncoder generator) cannot run in the reference either "
+                                      "(models/mygannet.py:224-227 builds an instance and then calls it)")
+        self.netg = NetG(getattr(args, "ich", 3)).to(self.device)
+        self.netd = NetD(args).to(self.device)
+        self.netg.apply(weights_init)
+        self.netd.apply(weights_init)
+        vdist.broadcast_module(self.netg)
+        vdist.broadcast_module(self.netd)
+
+        self.real_label, self.gout_label = 1.0, 0.0
+        self.l_adv = F.l2_loss
+        self.l_con = F.weighted_bce          # pos_weight=2 always: the reference overwrites its lambda (:265-266)
+        self.l_bce = F.bce_loss
+
+        self.optimizer_d = hoptim.Adam(self.netd.parameters(), lr=self.args.lr, betas=(self.args.beta1, 0.999))
+        self.optimizer_g = hoptim.Adam(self.netg.parameters(), lr=self.args.lr, betas=(self.args.beta1, 0.999))
+        self.reducer_g = vdist.GradReducer.for_optimizer(self.optimizer_g)
+        self.reducer_d = vdist.GradReducer.for_optimizer(self.optimizer_d)
+        self.gt_flow = self.pre_flow = None
+
+    def set_input(self, data, gt_flow=None, pre_flow=None):
+        super(MyGAN, self).set_input(data)
+        self.input_cl, self.gt_cl = F.to_cl(self.input), F.to_cl(self.gt)
+        B = self.input.shape[0]
+        if gt_flow is None:   # stand-ins for video_to_flow (lib/utils.py:94-129), SURVEY.md 8(d)
+            gt_flow = synthetic_flow(B, self.args.nfr, self.args.isize, seed=4321 + self.global_step)
+            pre_flow = synthetic_flow(B, self.args.nfr, self.args.isize, seed=8642 + self.global_step)
+        self.gt_flow = F.to_cl(gt_flow.to(self.device, non_blocking=True))
+        self.pre_flow = F.to_cl(pre_flow.to(self.device, non_blocking=True))
+
+    def forward_g(self):
+        self.predict = self.netg(self.input_cl)
+
+    def forward_d(self):
+        pre_3ch = F.gray2rgb(self.predict.detach())
+        gt_3ch = F.gray2rgb(self.gt_cl)
+        self.s_pred_real, self.s_feat_real, self.t_pred_real, self.t_feat_real = self.netd(gt_3ch, self.gt_flow)
+        self.s_pred_fake, self.s_feat_fake, self.t_pred_fake, self.t_feat_fake = self.netd(pre_3ch, self.pre_flow)
+
+    def backward_g(self):
+        # Everything netD sees is detached from netG (reference :279-286), so the adversarial term has no gradient
+        # path to netG; its gradients w.r.t. netD are discarded by optimizer_d.zero_grad() (:364).  It is therefore
+        # evaluated for its VALUE only, and only the reconstruction term is back-propagated.
+        err_g_adv_s = self.l_adv(self.s_feat_real.detach(), self.s_feat_fake.detach())
+        err_g_adv_t = self.l_adv(self.t_feat_real.detach(), self.t_feat_fake.detach())
+        err_g_adv = err_g_adv_s + err_g_adv_t
+        err_g_con = self.l_con(self.predict, self.gt_cl)
+        err_g = err_g_adv * self.args.w_adv + err_g_con * self.args.w_con
+        err_g.backward()
+        self.reducer_g.finish()
+        self.errors_dict.update({'g/err_g/train': err_g, 'g/err_g_adv/train': err_g_adv, 'g/err_g_adv_s/train': err_g_adv_s,
+                                 'g/err_g_adv_t/train': err_g_adv_t, 'g/err_g_con/train': err_g_con})
+
+    def backward_d(self):
+        err_d_real_s = self.l_bce(self.s_pred_real, self.real_label)
+        err_d_real_t = self.l_bce(self.t_pred_real, self.real_label)
+        err_d_fake_s = self.l_bce(self.s_pred_fake, self.gout_label)
+        err_d_fake_t = self.l_bce(self.t_pred_fake, self.gout_label)
+        err_d_real = (err_d_real_s + err_d_real_t) * 0.5
+        err_d_fake = (err_d_fake_s + err_d_fake_t) * 0.5
+        err_d = (err_d_real + err_d_fake) * 0.5
+        self.errors_dict.update({'d/err_d_real_s/train': err_d_real_s, 'd/err_d_real_t/train': err_d_real_t,
+                                 'd/err_d_fake_s/train': err_d_fake_s, 'd/err_d_fake_t/train': err_d_fake_t,
+                                 'd/err_d_real/train': err_d_real, 'd/err_d_fake/train': err_d_fake, 'd/err_d/train': err_d})
+        err_d.backward()
+        self.reducer_d.finish()
+
+    def reinit_d(self):
+        self.netd.apply(weights_init)
+        print('Reloading Net d')
+
+    def optimize_params(self):
+        self.netg.train()
+        self.netd.train()
+
+        self.forward_g()
+        self.forward_d()
+
+        self.optimizer_g.zero_grad()
+        self.backward_g()
+        self.optimizer_g.step()
+
+        self.optimizer_d.zero_grad()
+        self.backward_d()
+        self.optimizer_d.step()
+
+
+def make_args(nfr=16, isize=128, **kw):
+    d = dict(nfr=nfr, isize=isize, ich=3, batchsize=2, lr=2e-5, beta1=0.5, w_adv=1, w_con=10, pos_weight=2, freq=10 ** 9,
+             ep=1, model="mygan", result_root="./results", gpu=[0], ae=False)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
