@@ -111,6 +111,12 @@ def kats():
                                                         (32, 64, (3, 1, 1)), (512, 1024, (1, 3, 3))]}
 
 
+def args_defaults():
+    import lib.args as RAr  # reference flag system; parse() itself needs a CUDA device (lib/args.py:52), the parser does not
+    ns = RAr.Args().parser.parse_args([])
+    OUT_JSON["args_defaults"] = {k: v for k, v in vars(ns).items() if k not in ("tr_plist", "ts_plist", "result_root")}
+
+
 def spatiotemp():
     m = fill_module(RS.SpatioTemporalConv(3, 8, 3, padding=1), 11).train()
     x = seeded_tensor((2, 3, 4, 8, 8), 12).requires_grad_()
@@ -223,7 +229,7 @@ def mygan():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kats", "spatiotemp", "ganomaly", "anogan", "mygan"]
+    which = sys.argv[1:] or ["kats", "args_defaults", "spatiotemp", "ganomaly", "anogan", "mygan"]
     jp, npz = os.path.join(HERE, "reference_vectors.json"), os.path.join(HERE, "reference_vectors.npz")
     if os.path.exists(jp):
         OUT_JSON.update(json.load(open(jp)))
