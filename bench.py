@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying a hipGraph")
+    ap.add_argument("--layers", action="store_true", help="print a per-geometry table of the MFMA kernels to stderr")
     a = ap.parse_args()
 
     from vfd_gan_amd import dist as vdist
@@ -136,19 +138,39 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        model.optimize_params()
+    use_graph = not a.no_graph
     timer = None
-    if not a.no_kernel_timer:
-        timer = F.KernelTimer()
-        F.set_kernel_timer(timer)
+    if use_graph:
+        from vfd_gan_amd.graph import GraphedStep
+        step = GraphedStep(model, warmup=max(a.warmup, 2)).capture()      # eager warm-up steps + one captured step
+        run = step.replay
+        for _ in range(a.warmup):
+            run()
+    else:
+        run = model.optimize_params
+        for _ in range(a.warmup):
+            run()
+        if not a.no_kernel_timer:
+            timer = F.KernelTimer()
+            F.set_kernel_timer(timer)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        model.optimize_params()
+        run()
     barrier()
     elapsed = time.perf_counter() - t0
     F.set_kernel_timer(None)
+    timer_steps = a.steps
+    if use_graph and not a.no_kernel_timer:
+        # HIP events cannot be recorded inside a replayed graph: the per-kernel roofline is taken from an eager pass
+        # of the SAME step (same kernels, same launches) right after the timed region
+        timer_steps = min(a.steps, 5)
+        timer = F.KernelTimer()
+        F.set_kernel_timer(timer)
+        for _ in range(timer_steps):
+            model.optimize_params()
+        torch.cuda.synchronize()
+        F.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -166,11 +188,16 @@ def main():
                                    "to (%d,3,%d,%d), generalised pyramid 112-56-28-14-7, nz=100 ngf=64, full "
                                    "optimize_params (G fwd, 4 D fwd, backward_g, Adam, backward_d, Adam)"
                                    % (a.dtype, a.batch, a.batch * a.nfr, a.isize, a.isize),
-                       "global_batch": world * a.batch, "frames_per_clip": a.nfr, "parallelism": "dp%d" % world},
+                       "global_batch": world * a.batch, "frames_per_clip": a.nfr, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay of the captured step" if use_graph else "eager (one Python launch per kernel)"},
             "step_algorithmic_tflop": round(step_flops / 1e12, 3),
             "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
             "losses": {k: round(v, 6) for k, v in model.errors().items()},
         }
+        if timer is not None and a.layers:
+            for (name, geom), d in sorted(timer.by_geometry().items(), key=lambda kv: -kv[1]["ms"]):
+                print("%-34s %-62s x%-3d %8.1f us/launch %7.1f TF/s" % (name, geom, d["launches"] // timer_steps,
+                      d["ms"] * 1e3 / d["launches"], d["flops"] / max(d["ms"], 1e-9) / 1e9), file=sys.stderr)
         if timer is not None:
             summ = timer.summary()
             dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
@@ -179,10 +206,11 @@ def main():
             peak = MFMA_PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": None,
-                               "launches_per_step": d["launches"] // a.steps,
+                               "launches_per_step": d["launches"] // timer_steps,
+                               "timed_in": ("eager pass after the timed region" if use_graph else "timed region"),
                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
-            out["kernels"] = {k: {"launches_per_step": v["launches"] // a.steps, "ms_per_step": round(v["ms"] / a.steps, 3),
+            out["kernels"] = {k: {"launches_per_step": v["launches"] // timer_steps, "ms_per_step": round(v["ms"] / timer_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in sorted(summ.items())}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.isize, a.nfr)

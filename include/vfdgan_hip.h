@@ -94,11 +94,13 @@ int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T
                     void* stream);
 
 /* y = act(conv(x, packed) + bias).  `bias` float32[Cout] or NULL.
- * When stats != NULL (float32 [2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates the per-channel
- * sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
- * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106).                  */
+ * When stats != NULL (float32 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates
+ * the per-channel sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
+ * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106), one float atomic per
+ * channel and workgroup, spread over replica rows; vfd_bn_stats_from_sums folds the replicas.                */
+#define VFD_STATS_REPLICAS 64
 int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
-                     float* stats, void* ws, size_t ws_bytes, void* stream);
+                     float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Scratch bytes vfd_conv_forward wants for `d` (0 for most shapes).  Convolutions with few output pixels and a
  * long reduction (ganomaly Encoder final conv / NetD classifier: 512 pixels x K=25088) split K over workgroups
  * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
@@ -129,7 +131,7 @@ int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, flo
 size_t vfd_bn_workspace(int64_t rows, int C);
 int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float momentum, float* mean,
                  float* rstd, float* running_mean, float* running_var, void* ws, void* stream);
-/* Same, from the conv epilogue's sum / sum-of-squares buffer (stats[2][Cp]).                              */
+/* Same, from the conv epilogue's sum / sum-of-squares buffer (stats[VFD_STATS_REPLICAS][2][Cp]).         */
 int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean,
                            float* rstd, float* running_mean, float* running_var, void* stream);
 /* y = act((x-mean)*rstd*gamma + beta) */
@@ -206,6 +208,11 @@ int vfd_loss_backward(int kind, int dtype, const void* a, const void* b, float b
  * ---------------------------------------------------------------------------------------------- */
 int vfd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+/* Same update with the step counter on the device (*step_dev is incremented first; bc_dev = float[2] scratch for
+ * the bias corrections), so that a captured hipGraph of the whole training step can be replayed.              */
+int vfd_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                      float beta1, float beta2, float eps, int32_t* step_dev, float* bc_dev, float grad_scale,
+                      void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,13 +89,14 @@ def test_conv_fused_act_and_stats(dt, dev):
     pre = TF.conv3d(x, w, b, 1, 1)
     for act, slope, ref in [(_lib.ACT_LRELU, 0.2, TF.leaky_relu(pre, 0.2)), (_lib.ACT_SIGMOID, 0.0, torch.sigmoid(pre)),
                             (_lib.ACT_TANH, 0.0, torch.tanh(pre)), (_lib.ACT_LRELU, 64.0, TF.leaky_relu(pre, 64.0))]:
-        sums = torch.zeros(2 * 16, device=dev)
+        sums = F.new_stats_buffer(13, dev)
         yc = F.conv(F.to_cl(x.to(dev), dt), torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)), 1, 1, 0, False, act,
                     slope, stats=sums)
         assert relerr(yc.to_torch(), ref) < TOL[dt]
         s1 = pre.sum(dim=(0, 2, 3, 4))
         s2 = (pre * pre).sum(dim=(0, 2, 3, 4))
-        assert relerr(sums[:13], s1) < 1e-4 and relerr(sums[16:29], s2) < 1e-4
+        folded = sums.view(F.STATS_REPLICAS, 2, 16).sum(0)
+        assert relerr(folded[0, :13], s1) < 1e-4 and relerr(folded[1, :13], s2) < 1e-4
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])

@@ -81,8 +81,8 @@ def main():
             return torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev), need.value
         wf, nf = wsp(d_f)
         wd, ndb = wsp(d_d)
-        t_f = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_f), x.data_ptr(), pk_f.data_ptr(), 0, y.data_ptr(), 0, wf.data_ptr(), nf, st), a.iters)
-        t_d = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_d), gy.data_ptr(), pk_d.data_ptr(), 0, gx.data_ptr(), 0, wd.data_ptr(), ndb, st), a.iters)
+        t_f = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_f), x.data_ptr(), pk_f.data_ptr(), 0, y.data_ptr(), 0, 0, wf.data_ptr(), nf, st), a.iters)
+        t_d = timeit(lambda: lib.vfd_conv_forward(ctypes.byref(d_d), gy.data_ptr(), pk_d.data_ptr(), 0, gx.data_ptr(), 0, 0, wd.data_ptr(), ndb, st), a.iters)
 
         def wg():
             lib.vfd_conv_wgrad(ctypes.byref(d_f), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, st)

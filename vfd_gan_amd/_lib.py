@@ -35,7 +35,7 @@ SIGNATURES = {
     "vfd_unflatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_flatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_pack_filter": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
-    "vfd_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vfd_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "vfd_conv_workspace": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_sz)]),
     "vfd_wgrad_workspace": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int32),
                                     ctypes.POINTER(c_sz)]),
@@ -63,6 +63,7 @@ SIGNATURES = {
     "vfd_loss_forward": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_i64, c_int, c_f32, c_vp, c_vp]),
     "vfd_loss_backward": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_f32,
                                   c_vp]),
+    "vfd_adam_step_dev": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, c_vp]),
     "vfd_adam_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, ctypes.c_int32, c_f32,
                               c_vp]),
 }

@@ -153,7 +153,12 @@ __global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long ro
   const int Cp = (C + 7) & ~7;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double n = (double)rows, s1 = sums[c], s2 = sums[Cp + c];
+  double s1 = 0, s2 = 0;
+  for (int r = 0; r < VFD_STATS_REPLICAS; ++r) {      // replica rows written by the conv epilogues
+    s1 += sums[(size_t)r * 2 * Cp + c];
+    s2 += sums[(size_t)r * 2 * Cp + Cp + c];
+  }
+  const double n = (double)rows;
   const double mean = s1 / n;
   double m2 = s2 - s1 * mean;
   if (m2 < 0) m2 = 0;

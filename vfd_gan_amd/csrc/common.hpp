@@ -36,6 +36,33 @@ void vfd_set_error(const char* fmt, ...);
 static inline int cpad(int c) { return (c + 7) & ~7; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- division by a launch-constant: q = floor(m / d) for 0 <= m < 2^31 --------------------------------------
+// M = ceil(2^p / d), p = 31 + ceil(log2 d): m*M >> p is exact for every m < 2^31 (error term M*d - 2^p < 2^(p-31)).
+struct FastDiv {
+  uint32_t magic;
+  uint32_t shift;
+  uint32_t d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  const uint32_t p = 31 + l;
+  f.magic = (uint32_t)(((1ull << p) + d - 1) / d);
+  f.shift = p;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t m, const FastDiv& f) {
+  return (uint32_t)(((unsigned long long)m * f.magic) >> f.shift);
+}
+// q = m / d, r = m % d
+__device__ __forceinline__ void fdivmod(uint32_t m, const FastDiv& f, uint32_t& q, uint32_t& r) {
+  q = fdiv(m, f);
+  r = m - q * f.d;
+}
+
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

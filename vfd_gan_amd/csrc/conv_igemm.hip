@@ -17,6 +17,7 @@
 //     regular    : in = q*s - p + t            (t = tap, all k taps)          out = q
 //     transposed : in = q + c0 - t,  k = k0 + t*s, k0 = (r+p)%s, c0 = (r+p-k0)/s,  out = q*s + r
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +36,7 @@ struct ConvP {
   float slope;
   int ksplit;   // >1: K range split over blockIdx.z, raw f32 partial tiles go to ws[ksplit][M][Cop]
   float* ws;
+  int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
 };
 
 struct DimClass {  // per-dimension description of the taps of one output class
@@ -67,45 +69,57 @@ __device__ __forceinline__ DimClass make_dim(int transposed, int r, int k, int s
   return d;
 }
 
-// LDS tile: rows of 64 bytes (4 chunks of 16 B); chunk index XOR-swizzled by the row so that the ds_read_b128
-// fragment reads (16 rows x 4 chunks per wave-instruction) are bank-conflict free.
+// LDS tile: rows of 64*KSUB bytes (4*KSUB chunks of 16 B); the chunk index is XOR-swizzled by the row so that the
+// ds_read_b128 fragment reads (16 rows x 4 chunks per wave-instruction) are bank-conflict free
+// (checked against the gfx950 lane-group / 64-bank model of MI355X_MICROARCH.md for both row lengths).
+template <int KSUB>
+__device__ __forceinline__ int row_swizzle(int row) {
+  if constexpr (KSUB == 1) {
+    const int g = (row >> 2) & 3;
+    return (((g ^ (g >> 1)) & 1) << 1) | (g >> 1);
+  } else {
+    return (row >> 1) & 7;
+  }
+}
+template <int KSUB>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-  const int g = (row >> 2) & 3;
-  const int sw = (((g ^ (g >> 1)) & 1) << 1) | (g >> 1);
-  return row * 64 + ((chunk ^ sw) << 4);
+  return row * (64 * KSUB) + ((chunk ^ row_swizzle<KSUB>(row)) << 4);
 }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-  // one K-step = 32 bf16 = one v_mfma_f32_16x16x32_bf16 per 16x16 tile
-  template <int NI, int NJ>
+  // one 64-byte K sub-step = 32 bf16 = one v_mfma_f32_16x16x32_bf16 per 16x16 tile
+  template <int NI, int NJ, int KSUB>
   __device__ static __forceinline__ void step(const char* wt, const char* pt, int wrow0, int prow0, int lane,
                                               f32x4 (&acc)[NI][NJ]) {
-    bf16x8 a[NI], b[NJ];
     const int r = lane & 15, ch = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wt + lds_off(wrow0 + i * 16 + r, ch));
+    for (int ks = 0; ks < KSUB; ++ks) {
+      bf16x8 a[NI], b[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off(prow0 + j * 16 + r, ch));
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wt + lds_off<KSUB>(wrow0 + i * 16 + r, ch + 4 * ks));
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, ch + 4 * ks));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
   }
 };
 template <> struct Mma<float> {
-  // one K-step = 16 f32 = four v_mfma_f32_16x16x4_f32 per 16x16 tile (exact f32 FMA chain)
-  template <int NI, int NJ>
+  // one 64-byte K sub-step = 16 f32 = four v_mfma_f32_16x16x4_f32 per 16x16 tile (exact f32 FMA chain)
+  template <int NI, int NJ, int KSUB>
   __device__ static __forceinline__ void step(const char* wt, const char* pt, int wrow0, int prow0, int lane,
                                               f32x4 (&acc)[NI][NJ]) {
     const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 4 * KSUB; ++kk) {
       float a[NI], b[NJ];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const float*>(wt + lds_off(wrow0 + i * 16 + r, kk) + kq * 4);
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const float*>(wt + lds_off<KSUB>(wrow0 + i * 16 + r, kk) + kq * 4);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float*>(pt + lds_off(prow0 + j * 16 + r, kk) + kq * 4);
+      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const float*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, kk) + kq * 4);
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -114,21 +128,41 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+// 64 zero bytes: the source of every out-of-bounds / padded 16-byte chunk of an LDS-DMA load (the DMA has no
+// per-lane predicate that zero-fills, but its SOURCE address is per lane).
+__device__ uint4 g_zero_page[4];
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// Staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 16 tile rows per wave-instruction), STAGES-deep
+// ring, ONE raw s_barrier per K-step, counted vmcnt so that STAGES-2 future steps stay in flight across the barrier.
+// The LDS image is lane-linear per wave-instruction (row = lane/4, 16-byte slot = lane%4), so the bank swizzle of
+// lds_off() is applied to the SOURCE: slot s of row r is fed logical chunk s ^ sw(r).
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB>
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3 : ((STAGES * KSUB <= 3 && NI * NJ <= 16) ? 4 : 2))) void conv_igemm_kernel(const ConvP p) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int BK = 4 * VEC;
-  constexpr int WL = (TILE_C * 4 + 255) / 256;  // 16-byte chunks of the filter tile per thread
-  constexpr int PL = (TILE_P * 4 + 255) / 256;  // 16-byte chunks of the pixel tile per thread
-  static_assert(WAVES_C * WAVES_P == 4, "4 waves per workgroup");
+  constexpr int ROWB = 64 * KSUB;              // bytes of K per tile row and stage
+  constexpr int CPR = 4 * KSUB;                // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;                // tile rows per 1-KiB DMA wave-instruction
+  constexpr int BK = CPR * VEC;                // K elements per stage
+  constexpr int NW = TILE_C / RPI;             // wave-instructions per stage for the filter tile
+  constexpr int NP = TILE_P / RPI;             // ... for the pixel tile
+  constexpr int NWAVES = WAVES_C * WAVES_P;
+  constexpr int NWT = (NW + NWAVES - 1) / NWAVES;   // per wave
+  constexpr int NPT = (NP + NWAVES - 1) / NWAVES;
+  constexpr int STAGE_BYTES = (TILE_C + TILE_P) * ROWB;
+  constexpr int DUMP_OFF = STAGES * STAGE_BYTES;   // 1 KiB sink for the padding DMAs of waves without a real row group
+  static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * (TILE_C + TILE_P) * 64];
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + 1024];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_c0 = (wave % WAVES_C) * (NI * 16);
   const int wave_p0 = (wave / WAVES_C) * (NJ * 16);
 
@@ -154,10 +188,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   const int s_begin = ksl * steps_per;
   const int nsteps = max(0, min(nsteps_all - s_begin, steps_per));
 
-  // ---- per-thread load bookkeeping ----------------------------------------------------------------------
-  const int chunk = tid & 3;
-  const int rbase = tid >> 2;  // 0..63
-  // position of this thread's chunk inside the flattened K axis
+  // ---- per-thread DMA bookkeeping --------------------------------------------------------------------------
+  // lane -> (row within a 16-row group, physical 16-byte slot); logical K chunk = slot ^ swizzle(row)
+  const int lrow = lane / CPR;
+  // row = RPI * g + lrow with g = wave + NWAVES i: the swizzle of that row depends on the lane and on wave & 1 only
+  const int chunk = (lane % CPR) ^ row_swizzle<KSUB>(RPI * (wave & 1) + lrow);
+  // position of this thread's chunk inside the flattened K axis: (tap, channel offset kc)
   int kc, td, th, tw;
   {
     const int kflat = s_begin * BK + chunk * VEC;
@@ -168,16 +204,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     th = (dh.nk > 0) ? t % dh.nk : 0;
     td = (dh.nk > 0) ? t / dh.nk : 0;
   }
-  // pixel rows handled by this thread
-  int pn[PL], pid[PL], pih[PL], piw[PL];
+  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+  // filter rows of this thread: group index gw = wave + 4*i (valid while < NW)
+  long long wrow_off[NWT];      // element offset of (row, tap 0, channel 0), or -1
 #pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    const long long m = m0 + rbase + 64 * i;
-    if (m < Mcls && (rbase + 64 * i) < TILE_P) {
-      long long q = m;
-      const int qw = (int)(q % dw.Q); q /= dw.Q;
-      const int qh = (int)(q % dh.Q); q /= dh.Q;
-      const int qd = (int)(q % dd.Q); q /= dd.Q;
+  for (int i = 0; i < NWT; ++i) {
+    const int g = wave + NWAVES * i;
+    const int co = n0 + g * RPI + lrow;
+    wrow_off[i] = (g < NW && co < p.Cout) ? (long long)co * p.Kw : -1;
+  }
+  // pixel rows of this thread
+  int pn[NPT], pid[NPT], pih[NPT], piw[NPT];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int g = wave + NWAVES * i;
+    const long long m = m0 + g * RPI + lrow;
+    if (g < NP && m < Mcls) {
+      unsigned q = (unsigned)m;            // M < 2^31 (checked on the host): 32-bit divisions
+      const int qw = (int)(q % (unsigned)dw.Q); q /= (unsigned)dw.Q;
+      const int qh = (int)(q % (unsigned)dh.Q); q /= (unsigned)dh.Q;
+      const int qd = (int)(q % (unsigned)dd.Q); q /= (unsigned)dd.Q;
       pn[i] = (int)q;
       pid[i] = qd * dd.a + dd.c0;
       pih[i] = qh * dh.a + dh.c0;
@@ -186,57 +234,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
       pn[i] = -1; pid[i] = 0; pih[i] = 0; piw[i] = 0;
     }
   }
-  const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
-  const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
-
-  uint4 wreg[WL], preg[PL];
-  auto load_global = [&]() {
-    const bool kvalid = td < dd.nk && ntaps > 0;
+  // per-tap state (recomputed only when this thread's chunk moves to another tap)
+  long long wtap_off = 0;       // tap index * Cip inside a filter row
+  long long ppix_off[NPT];      // element offset of the gathered input pixel, or -1 (padding / out of range)
+  bool kvalid = false;
+  auto enter_tap = [&]() {
+    kvalid = (td < dd.nk) && ntaps > 0;
     const int tapidx = ((dd.k0 + td * dd.ks) * p.kh + (dh.k0 + th * dh.ks)) * p.kw + (dw.k0 + tw * dw.ks);
-#pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int row = rbase + 64 * i;
-      const int co = n0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && row < TILE_C && co < p.Cout)
-        v = *reinterpret_cast<const uint4*>(wg + (size_t)co * p.Kw + (size_t)tapidx * p.Cip + kc);
-      wreg[i] = v;
-    }
+    wtap_off = (long long)tapidx * p.Cip;
     const int od = td * dd.cs, oh = th * dh.cs, ow = tw * dw.cs;
 #pragma unroll
-    for (int i = 0; i < PL; ++i) {
+    for (int i = 0; i < NPT; ++i) {
       const int id = pid[i] + od, ih = pih[i] + oh, iw = piw[i] + ow;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && pn[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
-          (unsigned)iw < (unsigned)p.Wi) {
-        const size_t pix = ((size_t)(pn[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw;
-        v = *reinterpret_cast<const uint4*>(xg + pix * p.Cip + kc);
-      }
-      preg[i] = v;
+      const bool ok = kvalid && pn[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+                      (unsigned)iw < (unsigned)p.Wi;
+      ppix_off[i] = ok ? (((long long)(pn[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw) * p.Cip : -1;
+    }
+  };
+  enter_tap();
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  auto issue_stage = [&](int stage) {
+    char* wt = smem + stage * STAGE_BYTES;
+    char* pt = wt + TILE_C * ROWB;
+#pragma unroll
+    for (int i = 0; i < NWT; ++i) {
+      const int g = wave + NWAVES * i;   // wave-uniform
+      const char* src = (kvalid && wrow_off[i] >= 0) ? reinterpret_cast<const char*>(wg + wrow_off[i] + wtap_off + kc) : zero;
+      char* dst = (NW % NWAVES == 0 || g < NW) ? wt + g * 1024 : smem + DUMP_OFF;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int g = wave + NWAVES * i;
+      const char* src = (ppix_off[i] >= 0) ? reinterpret_cast<const char*>(xg + ppix_off[i] + kc) : zero;
+      char* dst = (NP % NWAVES == 0 || g < NP) ? pt + g * 1024 : smem + DUMP_OFF;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
     }
   };
   auto advance_k = [&]() {
     kc += BK;
-    while (kc >= p.Cip) {
-      kc -= p.Cip;
-      if (++tw >= dw.nk) {
-        tw = 0;
-        if (++th >= dh.nk) { th = 0; ++td; }
-      }
-    }
-  };
-  auto store_lds = [&](int buf) {
-    char* wt = smem + buf * (TILE_C + TILE_P) * 64;
-    char* pt = wt + TILE_C * 64;
-#pragma unroll
-    for (int i = 0; i < WL; ++i) {
-      const int row = rbase + 64 * i;
-      if (row < TILE_C) *reinterpret_cast<uint4*>(wt + lds_off(row, chunk)) = wreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PL; ++i) {
-      const int row = rbase + 64 * i;
-      if (row < TILE_P) *reinterpret_cast<uint4*>(pt + lds_off(row, chunk)) = preg[i];
+    if (kc >= p.Cip) {
+      do {
+        kc -= p.Cip;
+        if (++tw >= dw.nk) {
+          tw = 0;
+          if (++th >= dh.nk) { th = 0; ++td; }
+        }
+      } while (kc >= p.Cip);
+      enter_tap();
     }
   };
 
@@ -247,21 +292,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nsteps > 0) {
-    load_global();
-    store_lds(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-      const bool more = (s + 1) < nsteps;
-      if (more) {
-        advance_k();
-        load_global();
-      }
-      const char* wt = smem + (s & 1) * (TILE_C + TILE_P) * 64;
-      const char* pt = wt + TILE_C * 64;
-      Mma<T>::template step<NI, NJ>(wt, pt, wave_c0, wave_p0, lane, acc);
-      if (more) store_lds((s + 1) & 1);
-      __syncthreads();
+    // prologue: steps 0 .. STAGES-2 in flight (positions past the end of K read the zero page)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+      issue_stage(s);
+      advance_k();
     }
+    int stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      // this wave's DMAs of step s have landed once at most (STAGES-2) younger steps' DMAs are outstanding
+      {
+        constexpr int N = (NWT + NPT) * (STAGES - 2);
+        static_assert(N < 64, "vmcnt field");
+        // s_waitcnt encoding (gfx9+): vmcnt = imm[3:0] | imm[15:14] << 4; expcnt imm[6:4] = 7, lgkmcnt imm[11:8] = 15: no wait
+        __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+      }
+      // every wave's step-s DMAs landed AND every wave finished reading the stage the next issue overwrites
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int nstage = stage + STAGES - 1;
+      if (nstage >= STAGES) nstage -= STAGES;
+      issue_stage(nstage);          // step s + STAGES - 1 (zero page beyond the end: keeps the vmcnt accounting uniform)
+      advance_k();
+      const char* wt = smem + stage * STAGE_BYTES;
+      const char* pt = wt + TILE_C * ROWB;
+      Mma<T>::template step<NI, NJ, KSUB>(wt, pt, wave_c0, wave_p0, lane, acc);
+      if (++stage == STAGES) stage = 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0): drain the trailing zero-page DMAs before LDS is released
   }
 
   const int cq = (lane >> 4) * 4;
@@ -282,40 +340,50 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
   }
 
   // ---- epilogue: bias, statistics, activation, channels-last store --------------------------------------
+  // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time)
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  float ssum[NI][4], ssq[NI][4];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
-
+  long long opix[NJ];     // output pixel offset in elements (pixel * Cop), or -1
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
-    const bool mvalid = m < Mcls;
-    size_t opix = 0;
-    if (mvalid) {
-      long long q = m;
-      const int qw = (int)(q % dw.Q); q /= dw.Q;
-      const int qh = (int)(q % dh.Q); q /= dh.Q;
-      const int qd = (int)(q % dd.Q); q /= dd.Q;
+    opix[j] = -1;
+    if (m < Mcls) {
+      unsigned q = (unsigned)m;
+      const int qw = (int)(q % (unsigned)dw.Q); q /= (unsigned)dw.Q;
+      const int qh = (int)(q % (unsigned)dh.Q); q /= (unsigned)dh.Q;
+      const int qd = (int)(q % (unsigned)dd.Q); q /= (unsigned)dd.Q;
       const int n = (int)q;
-      opix = ((size_t)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r;
+      opix[j] = ((((long long)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r)) * p.Cop;
     }
+  }
+  const bool want_stats = p.stats != nullptr;
+  // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS, reusing the staging ring) -> ONE float atomic
+  // per channel and workgroup into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of
+  // workgroups adding into the same 2*Cout addresses; bn_from_sums folds the replicas).
+  float* red = reinterpret_cast<float*>(smem);     // [2][TILE_C][WAVES_P]
+  if (want_stats) __syncthreads();                 // every wave is done reading the last stage
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = n0 + wave_c0 + i * 16 + cq;
+  for (int i = 0; i < NI; ++i) {
+    const int c = n0 + wave_c0 + i * 16 + cq;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool mvalid = opix[j] >= 0;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = acc[i][j][r];
-        if (p.bias != nullptr && (c + r) < p.Cout) t += p.bias[c + r];
-        if (p.stats != nullptr && mvalid) { ssum[i][r] += t; ssq[i][r] += t * t; }
-        v[r] = act_apply(t, p.act, p.slope);
-        if ((c + r) >= p.Cout) v[r] = 0.f;  // keep pad channels zero (sigmoid(0) != 0)
+        const float t = acc[i][j][r] + b4[r];
+        if (want_stats && mvalid) { s1[r] += t; s2[r] += t * t; }
+        v[r] = ((c + r) < p.Cout) ? act_apply(t, p.act, p.slope) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
       }
       if (mvalid && c < p.Cop) {
-        T* dst = yg + opix * p.Cop + c;
+        T* dst = yg + opix[j] + c;
         if constexpr (sizeof(T) == 2) {
           uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
           *reinterpret_cast<uint2*>(dst) = o;
@@ -324,21 +392,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         }
       }
     }
-  }
-  if (p.stats != nullptr) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
+    if (want_stats) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = ssum[i][r], b = ssq[i][r];
+        float a = s1[r], b = s2[r];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        const int c = n0 + wave_c0 + i * 16 + cq + r;
-        if ((lane & 15) == 0 && c < p.Cout) {
-          atomicAdd(p.stats + c, a);
-          atomicAdd(p.stats + p.Cop + c, b);
+        if ((lane & 15) == 0) {
+          const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
+          red[cl * WAVES_P + (wave / WAVES_C)] = a;
+          red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
         }
       }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    float* rep = p.stats + (size_t)((blockIdx.x + blockIdx.z) % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
+      const int which = t / TILE_C, cl = t - which * TILE_C;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
+      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);
+    }
   }
 }
 
@@ -378,21 +455,21 @@ int pick_ksplit(const ConvP& p, long long M, int bk) {
   return ks < 2 ? 1 : (int)ks;
 }
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ>
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB>
 int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
   const long long mb = (maxM + TILE_P - 1) / TILE_P;
   if (mb <= 0) return VFD_OK;
-  if (mb > 0x7fffffffLL) { vfd_set_error("conv: too many pixel blocks"); return VFD_EINVAL; }
+  if (maxM >= 0x7fffffffLL) { vfd_set_error("conv: %lld output pixels per class exceed 2^31", maxM); return VFD_EINVAL; }
   ConvP q = p;
-  q.ksplit = pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * Elem<T>::VEC);
+  q.ksplit = pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
   dim3 grid((unsigned)mb, (unsigned)((p.Cout + TILE_C - 1) / TILE_C), (unsigned)(ncls * q.ksplit));
   if (grid.y > 65535u || grid.z > 65535u) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ>), grid, dim3(256), 0, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
   if (q.ksplit > 1) {
     const long long total = maxM * (p.Cop >> 3);
@@ -407,10 +484,19 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
 
 template <typename T>
 int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
-  if (p.Cout > 64) return launch_cfg<T, 2, 2, 4, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   // 128 ch x 128 px
-  if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   //  64 ch x 256 px
-  if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4>(p, maxM, ncls, st, ws_bytes, ws_query);   //  32 ch x 256 px
-  return launch_cfg<T, 1, 4, 1, 4>(p, maxM, ncls, st, ws_bytes, ws_query);                    //  16 ch x 256 px
+  const int variant = p.variant;   // tuning override (env VFD_IGEMM_VARIANT); 0 = heuristic below
+  if (p.Cout > 64) {
+    // measured on the ganomaly pyramid (tools/layer_bench.py, bf16): 256c x 128p (8 waves) 750-825 TFLOP/s for
+    // Cout >= 256; 128c x 256p (8 waves) 540-740 for Cout = 128; the 4-wave 128 x 128 tile 520-690.
+    if (variant == 1) return launch_cfg<T, 2, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 128c x 128p, 4 waves
+    if (variant == 2) return launch_cfg<T, 2, 2, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);   // ... 128-byte rows
+    if (variant == 5 || (variant == 0 && p.Cout <= 128))
+      return launch_cfg<T, 2, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                   // 128c x 256p, 8 waves
+    return launch_cfg<T, 4, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                     // 256c x 128p, 8 waves
+  }
+  if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  64 ch x 256 px
+  if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  32 ch x 256 px
+  return launch_cfg<T, 1, 4, 1, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                    //  16 ch x 256 px
 }
 
 }  // namespace
@@ -439,7 +525,7 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
 }
 
 static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
-                         void* ws, size_t ws_bytes, size_t* ws_query, void* stream) {
+                         size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
   vfd_conv_desc dn = *d_in;
   if (dn.transposed) {
@@ -455,6 +541,8 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   if (rc != VFD_OK) return rc;
   if (ws_query == nullptr) {
     VFD_REQUIRE(x && packed && y, "conv: null tensor pointer");
+    VFD_REQUIRE(stats == nullptr || stats_bytes >= (size_t)VFD_STATS_REPLICAS * 2 * cpad(d->Cout) * sizeof(float),
+                "conv: statistics buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) floats", stats_bytes);
     VFD_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y | (uintptr_t)ws) & 15) == 0, "conv: tensors must be 16-byte aligned");
   }
   ConvP p;
@@ -467,6 +555,10 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   p.Kw = d->kd * d->kh * d->kw * p.Cip;
   p.act = d->act; p.slope = d->slope;
   p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
+  {
+    static const int v = getenv("VFD_IGEMM_VARIANT") ? atoi(getenv("VFD_IGEMM_VARIANT")) : 0;
+    p.variant = v;
+  }
   long long maxM;
   int ncls = 1;
   if (!d->transposed) {
@@ -483,10 +575,32 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
 extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes) {
   VFD_REQUIRE(bytes != nullptr, "conv_workspace: null result pointer");
   float dummy;
-  return conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, want_stats ? &dummy : nullptr, nullptr, 0, bytes, nullptr);
+  return conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, want_stats ? &dummy : nullptr, 0, nullptr, 0, bytes, nullptr);
 }
 
 extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
-                                float* stats, void* ws, size_t ws_bytes, void* stream) {
-  return conv_dispatch(d, x, packed, bias, y, stats, ws, ws_bytes, nullptr, stream);
+                                float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
+  return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, ws, ws_bytes, nullptr, stream);
+}
+
+// Tuning aid (not part of the public ABI): resident workgroups per CU the runtime grants the main kernels.
+extern "C" int vfd_debug_occupancy(int* out, int n) {
+  int k = 0, v = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return -1;
+  if (k < n) out[k++] = (int)prop.maxSharedMemoryPerMultiProcessor;
+  if (k < n) out[k++] = (int)prop.sharedMemPerBlock;
+  if (k < n) out[k++] = prop.multiProcessorCount;
+#define OCC(...)                                                                                       \
+  if (k < n) {                                                                                         \
+    v = -1;                                                                                            \
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, (const void*)(__VA_ARGS__), 256, 0);        \
+    out[k++] = v;                                                                                      \
+  }
+  OCC(conv_igemm_kernel<bf16_t, 2, 2, 4, 4, 3, 1>)
+  OCC(conv_igemm_kernel<bf16_t, 2, 2, 4, 4, 2, 2>)
+  OCC(conv_igemm_kernel<bf16_t, 1, 4, 4, 4, 3, 1>)
+  OCC(conv_igemm_kernel<bf16_t, 1, 4, 1, 4, 3, 1>)
+#undef OCC
+  return k;
 }

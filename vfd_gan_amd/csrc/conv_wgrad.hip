@@ -26,28 +26,37 @@ struct WgP {
   int ncols;                    // kd*kh*kw*Cgp
   long long M;                  // N*Qd*Qh*Qw
   long long chunkM;             // pixels per split (multiple of the K step)
+  FastDiv fQw, fQh, fQd;        // pixel index -> (n, qd, qh, qw) without integer division
 };
 
+// Tile geometry: [KP pixel rows][128 channels], rows of ROWB bytes = CPR 16-byte chunks, no padding (the tiles are
+// written by LDS-DMA, which is lane-linear); bank conflicts of the K-strided fragment reads are removed by XOR-ing
+// the chunk index with a function of the pixel row, applied on the DMA's SOURCE side.
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> {
   static constexpr int KP = 32;       // pixels per K step
-  static constexpr int PITCH = 288;   // bytes per pixel row of a 128-channel tile (256 + 32 pad)
+  static constexpr int ROWB = 256;
+  // ds_read_b64_tr_b16: a half-wave touches 8 pixel rows x 32 B; chunk ^ 2*(row&7) spreads them over all 64 banks
+  __device__ static __forceinline__ int swz(int row) { return 2 * (row & 7); }
 };
 template <> struct WgTraits<float> {
   static constexpr int KP = 16;
-  static constexpr int PITCH = 576;   // 512 + 64 pad
+  static constexpr int ROWB = 512;
+  // ds_read_b32: a half-wave touches 2 pixel rows x 64 B; chunk ^ 4*(row&1) puts them on different bank halves
+  __device__ static __forceinline__ int swz(int row) { return 4 * (row & 1); }
 };
 
-// fragment loads: tile is [KP pixel rows][128 channels], `c0` = first channel of the 16-wide fragment
+// fragment loads: `c0` = first channel of the 16-wide fragment
 __device__ __forceinline__ bf16x8 frag_tr_bf16(const char* tile, int c0, int lane) {
   // lane = 16g + 4q + pp supplies the address of pixel row (4g + q [+16]), channels c0 + 4pp..+3;
   // it receives channel c0 + (lane & 15) of the 4 rows of its group -> MFMA k = 8g + j  (j<4: first read)
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  const char* a0 = tile + (4 * g + q) * WgTraits<bf16_t>::PITCH + (c0 + 4 * pp) * 2;
-  const char* a1 = a0 + 16 * WgTraits<bf16_t>::PITCH;
+  const int row = 4 * g + q;
+  const int ch = c0 + 4 * pp;
+  const int off = row * 256 + ((((ch >> 3) ^ WgTraits<bf16_t>::swz(row)) << 4) | ((ch & 4) << 1));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a1));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 16 * 256));   // row + 16: same row & 7
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -69,6 +78,9 @@ template <> struct WgMma<bf16_t> {
   }
 };
 template <> struct WgMma<float> {
+  __device__ static __forceinline__ int off(int px, int c) {
+    return px * 512 + ((((c >> 2) ^ WgTraits<float>::swz(px)) << 4) | ((c & 3) << 2));
+  }
   __device__ static __forceinline__ void step(const char* st, const char* gt, int r0, int c0, int lane,
                                               f32x4 (&acc)[4][4]) {
     const int r = lane & 15, kq = lane >> 4;
@@ -77,9 +89,9 @@ template <> struct WgMma<float> {
       float a[4], b[4];
       const int px = kk * 4 + kq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float*>(st + px * WgTraits<float>::PITCH + (r0 + i * 16 + r) * 4);
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float*>(st + off(px, r0 + i * 16 + r));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float*>(gt + px * WgTraits<float>::PITCH + (c0 + j * 16 + r) * 4);
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float*>(gt + off(px, c0 + j * 16 + r));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -88,19 +100,27 @@ template <> struct WgMma<float> {
   }
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
+__device__ uint4 g_wg_zero_page[4];   // source of every masked 16-byte chunk (see conv_igemm.hip)
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <typename T, int STAGES>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgP p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KP = WgTraits<T>::KP;
-  constexpr int PITCH = WgTraits<T>::PITCH;
-  constexpr int CPR = 128 / VEC;         // 16-byte chunks per tile row (16 bf16 / 32 f32)
-  constexpr int RPT = KP * CPR / 256;    // rows per thread (2)
-  constexpr int RSTEP = 256 / CPR;       // pixel-row stride between a thread's rows
-  constexpr int TILE_BYTES = KP * PITCH;
+  constexpr int ROWB = WgTraits<T>::ROWB;
+  constexpr int CPR = ROWB / 16;         // 16-byte chunks per tile row (16 bf16 / 32 f32)
+  constexpr int RPI = 64 / CPR;          // pixel rows per 1-KiB DMA wave-instruction (4 / 2)
+  constexpr int NINST = KP / RPI;        // DMA instructions per tile and stage (8)
+  constexpr int NT = NINST / 4;          // per wave and tile (2)
+  constexpr int TILE_BYTES = KP * ROWB;  // 8 KiB
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  static_assert(NINST == 8, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr0 = (wave & 1) * 64, wc0 = (wave >> 1) * 64;
   const int r0 = blockIdx.y * 128;    // first S channel of this tile
   const int nb0 = blockIdx.x * 128;   // first flattened column of this tile
@@ -109,12 +129,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
   if (mend > p.M) mend = p.M;
   const int nsteps = (mbeg < mend) ? (int)((mend - mbeg + KP - 1) / KP) : 0;
 
-  const int chunk = tid % CPR;
-  const int prow = tid / CPR;
-  // S column of this thread
+  // DMA bookkeeping: lane -> (pixel row within a group, physical slot); logical chunk = slot ^ swz(row)
+  const int lrow = lane / CPR;
+  const int chunk = (lane % CPR) ^ WgTraits<T>::swz(RPI * (wave & 1) + lrow);   // row & 7 depends on wave & 1 and lrow only
   const int sc = r0 + chunk * VEC;
   const bool sc_ok = sc < p.Csp;
-  // G column of this thread -> (tap, channel)
   const int col = nb0 + chunk * VEC;
   const bool col_ok = col < p.ncols;
   int gt_d = 0, gt_h = 0, gt_w = 0, gch = 0;
@@ -125,41 +144,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     gt_h = t % p.kh; gt_d = t / p.kh;
   }
   const int off_d = gt_d - p.pd, off_h = gt_h - p.ph, off_w = gt_w - p.pw;
-
   const T* __restrict__ Sg = reinterpret_cast<const T*>(p.S);
   const T* __restrict__ Gg = reinterpret_cast<const T*>(p.G);
+  const char* zero = reinterpret_cast<const char*>(g_wg_zero_page);
 
-  uint4 sreg[RPT], greg[RPT];
-  auto load_global = [&](int s) {
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const long long m = mbeg + (long long)s * KP + prow + RSTEP * i;
-      uint4 sv = make_uint4(0, 0, 0, 0), gv = make_uint4(0, 0, 0, 0);
-      if (m < mend) {
-        if (sc_ok) sv = *reinterpret_cast<const uint4*>(Sg + (size_t)m * p.Csp + sc);
-        if (col_ok) {
-          unsigned q = (unsigned)m;
-          const int qw = q % (unsigned)p.Qw; q /= (unsigned)p.Qw;
-          const int qh = q % (unsigned)p.Qh; q /= (unsigned)p.Qh;
-          const int qd = q % (unsigned)p.Qd; q /= (unsigned)p.Qd;
-          const int gd = qd * p.sd + off_d, gh = qh * p.sh + off_h, gw = qw * p.sw + off_w;
-          if ((unsigned)gd < (unsigned)p.Gd && (unsigned)gh < (unsigned)p.Gh && (unsigned)gw < (unsigned)p.Gw) {
-            const size_t pix = ((size_t)((int)q * p.Gd + gd) * p.Gh + gh) * p.Gw + gw;
-            gv = *reinterpret_cast<const uint4*>(Gg + pix * p.Cgp + gch);
-          }
-        }
-      }
-      sreg[i] = sv; greg[i] = gv;
-    }
-  };
-  auto store_lds = [&](int buf) {
-    char* st = smem + buf * 2 * TILE_BYTES;
+  auto issue_stage = [&](int stage, int s) {
+    char* st = smem + stage * STAGE_BYTES;
     char* gt = st + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int row = prow + RSTEP * i;
-      *reinterpret_cast<uint4*>(st + row * PITCH + chunk * 16) = sreg[i];
-      *reinterpret_cast<uint4*>(gt + row * PITCH + chunk * 16) = greg[i];
+    for (int i = 0; i < NT; ++i) {
+      const int g = wave + 4 * i;
+      const long long m = mbeg + (long long)s * KP + g * RPI + lrow;
+      const bool mok = m < mend;
+      const char* ssrc = (mok && sc_ok) ? reinterpret_cast<const char*>(Sg + (size_t)m * p.Csp + sc) : zero;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)ssrc, (lds_void_t*)(st + g * 1024), 16, 0, 0);
+      const char* gsrc = zero;
+      if (mok && col_ok) {
+        uint32_t q = (uint32_t)m, qw, qh, qd;
+        fdivmod(q, p.fQw, q, qw);
+        fdivmod(q, p.fQh, q, qh);
+        fdivmod(q, p.fQd, q, qd);
+        const int gd = (int)qd * p.sd + off_d, gh = (int)qh * p.sh + off_h, gw = (int)qw * p.sw + off_w;
+        if ((unsigned)gd < (unsigned)p.Gd && (unsigned)gh < (unsigned)p.Gh && (unsigned)gw < (unsigned)p.Gw) {
+          const size_t pix = ((size_t)((int)q * p.Gd + gd) * p.Gh + gh) * p.Gw + gw;
+          gsrc = reinterpret_cast<const char*>(Gg + pix * p.Cgp + gch);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)(gt + g * 1024), 16, 0, 0);
     }
   };
 
@@ -170,17 +181,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (nsteps > 0) {
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_stage(s, s);     // steps past the end read the zero page
+    int stage = 0;
     for (int s = 0; s < nsteps; ++s) {
-      const bool more = (s + 1) < nsteps;
-      if (more) load_global(s + 1);
-      const char* st = smem + (s & 1) * 2 * TILE_BYTES;
+      {
+        constexpr int N = 2 * NT * (STAGES - 2);
+        __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));   // vmcnt(N)
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int nstage = stage + STAGES - 1;
+      if (nstage >= STAGES) nstage -= STAGES;
+      issue_stage(nstage, s + STAGES - 1);
+      const char* st = smem + stage * STAGE_BYTES;
       WgMma<T>::step(st, st + TILE_BYTES, wr0, wc0, lane, acc);
-      if (more) store_lds((s + 1) & 1);
-      __syncthreads();
+      if (++stage == STAGES) stage = 0;
     }
+    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0)
   }
 
   // slab store: ws[z][r][col], D[row = r (lane>>4)*4+reg][col = lane&15]
@@ -254,10 +272,11 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   g.T = d->kd * d->kh * d->kw;
   p.ncols = g.T * p.Cgp;
   p.M = (long long)d->N * p.Qd * p.Qh * p.Qw;
+  p.fQw = make_fastdiv((uint32_t)p.Qw); p.fQh = make_fastdiv((uint32_t)p.Qh); p.fQd = make_fastdiv((uint32_t)p.Qd);
   VFD_REQUIRE(p.M < 0x7fffffffLL, "wgrad: pixel count %lld exceeds 2^31", p.M);
   const int KP = d->dtype == VFD_BF16 ? 32 : 16;
   const long long tiles = (long long)((p.Cs + 127) / 128) * ((p.ncols + 127) / 128);
-  long long nsplit = 2048 / tiles;
+  long long nsplit = 768 / tiles;   // one round of 3 resident workgroups per CU
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit > 256) nsplit = 256;
@@ -297,9 +316,9 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   dim3 grid((g.p.ncols + 127) / 128, (g.p.Cs + 127) / 128, g.nsplit);
   VFD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, "wgrad: grid too large");
   if (d->dtype == VFD_BF16)
-    hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), g.p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, as_stream(stream), g.p);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), 0, as_stream(stream), g.p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 3>), grid, dim3(256), 0, as_stream(stream), g.p);
   VFD_CHECK_LAUNCH("conv_wgrad");
   return VFD_OK;
 }

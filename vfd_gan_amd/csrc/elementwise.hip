@@ -489,6 +489,51 @@ extern "C" int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows,
   return VFD_OK;
 }
 
+// hipGraph-replayable form: the step counter lives on the device.  state = {int32 step; float bc1; float bc2_sqrt;}
+__global__ void adam_prepare_kernel(int* step, float* bc, float b1, float b2) {
+  const int t = *step + 1;
+  *step = t;
+  bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+  bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long long n, float lr, float b1, float b2, float eps, const float* __restrict__ bc, float gscale) {
+  const float bc1 = bc[0], bc2_sqrt = bc[1];
+  const long long n4 = (n + 3) >> 2;   // arenas are padded to a multiple of 64 floats
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = G[k] * gscale;
+      M[k] = b1 * M[k] + (1.f - b1) * gk;
+      V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+      P[k] -= (lr / bc1) * (M[k] / (sqrtf(V[k]) / bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+extern "C" int vfd_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, int32_t* step_dev, float* bc_dev, float grad_scale,
+                                 void* stream) {
+  VFD_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev && bc_dev && n > 0 && (n & 3) == 0,
+              "adam_dev: bad arguments (n must be a multiple of 4)");
+  VFD_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+              "adam_dev: arenas must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_dev, bc_dev, beta1, beta2);
+  VFD_CHECK_LAUNCH("adam_prepare");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n / 4)), dim3(EW_THREADS), 0, as_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, (long long)n, lr, beta1, beta2, eps, bc_dev, grad_scale);
+  VFD_CHECK_LAUNCH("adam_dev");
+  return VFD_OK;
+}
+
 extern "C" int vfd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t step, float grad_scale, void* stream) {
   VFD_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam: bad arguments");

@@ -34,6 +34,14 @@ def cpad(c):
     return (c + 7) & ~7
 
 
+STATS_REPLICAS = 64  # == VFD_STATS_REPLICAS (include/vfdgan_hip.h)
+
+
+def new_stats_buffer(channels, device):
+    """Zeroed [STATS_REPLICAS][2][CPAD(C)] float32 buffer for a conv epilogue's BatchNorm partial sums."""
+    return torch.zeros(STATS_REPLICAS * 2 * cpad(channels), dtype=torch.float32, device=device)
+
+
 class ClTensor:
     """A channels-last activation block plus its logical channel count.
 
@@ -249,10 +257,22 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
+    def by_geometry(self):
+        """(kernel, geometry) -> launches / total ms / TFLOP/s; for tuning (bench.py --layers)."""
+        torch.cuda.synchronize()
+        out = {}
+        for rec in self.records:
+            name, flops, e0, e1 = rec[:4]
+            d = out.setdefault((name, rec[4] if len(rec) > 4 else ""), {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
+        for name, flops, e0, e1, *_ in self.records:
             d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
@@ -271,8 +291,16 @@ def _igemm_name(desc):
     """Name of the conv_igemm instantiation vfd_conv_forward dispatches to (conv_igemm.hip: launch<T>)."""
     t = "bf16" if desc.dtype == _lib.BF16 else "f32"
     c = desc.Cout
-    tile = "128c_x_128p" if c > 64 else ("64c_x_256p" if c > 32 else ("32c_x_256p" if c > 16 else "16c_x_256p"))
+    tile = ("256c_x_128p" if c > 128 else "128c_x_256p") if c > 64 else (
+        "64c_x_256p" if c > 32 else ("32c_x_256p" if c > 16 else "16c_x_256p"))
     return "conv_igemm<%s,%s>" % (t, tile)
+
+
+def _geom_str(desc, stats=None):
+    return "%s N%d %dx%dx%d c%d -> %dx%dx%d c%d k%d%d%d s%d%d%d p%d%d%d%s%s" % (
+        "T" if desc.transposed else "C", desc.N, desc.Di, desc.Hi, desc.Wi, desc.Cin, desc.Do, desc.Ho, desc.Wo, desc.Cout,
+        desc.kd, desc.kh, desc.kw, desc.sd, desc.sh, desc.sw, desc.pd, desc.ph, desc.pw,
+        " act%d" % desc.act if desc.act else "", " stats" if stats is not None else "")
 
 
 def _conv_flops(desc):
@@ -294,10 +322,11 @@ def _conv_launch(desc, x, packed, bias, out, stats=None):
     check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
     ws = torch.empty(need.value, dtype=torch.uint8, device=x.device) if need.value else None
     check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
-                               ptr(stats), ptr(ws), need.value, stream()), "conv_forward")
+                               ptr(stats), stats.numel() * 4 if stats is not None else 0, ptr(ws), need.value, stream()),
+          "conv_forward")
     if timer is not None:
         e1.record()
-        timer.records.append((_igemm_name(desc), _conv_flops(desc), e0, e1))
+        timer.records.append((_igemm_name(desc), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
 
 
 class _Conv(torch.autograd.Function):
@@ -362,7 +391,8 @@ class _Conv(torch.autograd.Function):
                   "conv_wgrad")
             if timer is not None:
                 e1.record()
-                timer.records.append(("conv_wgrad<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"), _conv_flops(desc), e0, e1))
+                timer.records.append(("conv_wgrad<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"), _conv_flops(desc), e0, e1,
+                                      _geom_str(desc)))
             gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
             check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -416,6 +446,8 @@ class _BnAct(torch.autograd.Function):
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         dtc = dtype_code(x.dtype)
         if sums is not None:
+            if sums.numel() < STATS_REPLICAS * 2 * cpad(C):
+                raise RuntimeError("bn_act: statistics buffer too small (use functional.new_stats_buffer)")
             check(lib.vfd_bn_stats_from_sums(sums.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
                                              ptr(running_mean), ptr(running_var), stream()), "bn_stats_from_sums")
         else:

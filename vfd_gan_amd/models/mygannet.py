@@ -28,7 +28,7 @@ def _conv_bn_act(block, x, slope):
     """SpatioTemporalConv -> BatchNorm3d -> LeakyReLU(slope) with the BatchNorm statistics taken from the temporal
     conv's epilogue (bf16) and normalise+activate in one pass."""
     if block.bn.training and hnn.use_epilogue_stats(x):
-        sums = torch.zeros(2 * F.cpad(block.bn.num_features), dtype=torch.float32, device=x.t.device)
+        sums = F.new_stats_buffer(block.bn.num_features, x.t.device)
         x = block.conv(x, stats=sums)
         return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=sums)
     x = block.conv(x)

@@ -183,7 +183,7 @@ def run_fused(mods, x):
                 i += 2
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and use_epilogue_stats(x):
-                sums = torch.zeros(2 * F.cpad(m.out_channels), dtype=torch.float32, device=x.t.device)
+                sums = F.new_stats_buffer(m.out_channels, x.t.device)
                 x = m(x, stats=sums)
                 a = _act_of(mods[i + 2]) if i + 2 < n else None
                 if a is not None:

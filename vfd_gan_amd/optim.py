@@ -45,6 +45,8 @@ class Adam(torch.optim.Optimizer):
                 p.data = view
                 p.grad = self.grad_arena[o:o + n].view(p.shape)
         self._step = 0
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side counter (graph replay)
+        self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
         self.grad_scale = 1.0  # set to 1/world_size when gradients are summed over ranks
         F.invalidate_weight_cache()
 
@@ -64,20 +66,22 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closure")
         g = self.param_groups[0]
-        self._step += 1
+        self._step += 1      # host mirror; the kernel uses the device counter so a captured step can be replayed
         b1, b2 = g["betas"]
-        check(load().vfd_adam_step(self.param_arena.data_ptr(), self.grad_arena.data_ptr(), self.exp_avg.data_ptr(),
-                                   self.exp_avg_sq.data_ptr(), self._total, float(g["lr"]), float(b1), float(b2),
-                                   float(g["eps"]), self._step, float(self.grad_scale), stream()), "adam_step")
+        check(load().vfd_adam_step_dev(self.param_arena.data_ptr(), self.grad_arena.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self._total, float(g["lr"]), float(b1), float(b2),
+                                       float(g["eps"]), self._step_dev.data_ptr(), self._bc_dev.data_ptr(),
+                                       float(self.grad_scale), stream()), "adam_step_dev")
         F.invalidate_weight_cache()
 
     # ---- resume support (the reference saves no optimiser state) -------------------------------
     def state_dict(self):
-        return {"step": self._step, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        return {"step": int(self._step_dev.item()), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         self._step = int(sd["step"])
+        self._step_dev.fill_(self._step)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s in zip(self.param_groups, sd.get("param_groups", [])):
