@@ -1,0 +1,39 @@
+"""GPU test of the data-parallel step logic: 2 ranks (gloo, both on cuda:0) stepping identical clips must reproduce
+the single-process run — eager (hook-driven bucketed reductions) and graph mode (phase graphs + reductions between)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(mode, world, tmp_path):
+    out = str(tmp_path / ("%s_%d.json" % (mode, world)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), mode, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o.decode()[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_match_single_process(mode, dev, tmp_path):
+    one = _run(mode, 1, tmp_path)
+    two = _run(mode, 2, tmp_path)
+    assert two["world"] == 2
+    for k, v in one["errors"].items():
+        assert abs(two["errors"][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, two["errors"][k], v)
+    for k, v in one["sums"].items():
+        assert abs(two["sums"][k] - v) <= 1e-4 * max(abs(v), 1.0), (k, two["sums"][k], v)

@@ -88,7 +88,8 @@ class GradReducer:
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.handles = []
-        self.enabled = True
+        self.enabled = True      # toggled by the step (a frozen net's gradients are not reduced)
+        self.suspended = False   # set while a hipGraph capture is open: no collective may be issued then
         self._hooks = []
         for i, p in enumerate(self.params):
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
@@ -116,13 +117,21 @@ class GradReducer:
 
     def _make_hook(self, i):
         def hook(_param):
-            if not self.enabled:
+            if not self.enabled or self.suspended:
                 return
             b = self.owner[i]
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 self._launch(b)
         return hook
+
+    def reduce_all(self):
+        """All buckets now, on the current stream (used between captured graph phases, where the backward that
+        produced the gradients is a graph replay and no autograd hook fires)."""
+        if self.world > 1:
+            for lo, hi, _ in self.buckets:
+                tdist.all_reduce(self.arena[lo:hi], op=tdist.ReduceOp.SUM)
+        self.reset()
 
     def finish(self):
         """Launch whatever has not been launched (parameters that received no gradient), wait for all buckets

@@ -14,13 +14,17 @@ from . import functional as F
 
 
 class GraphedStep:
-    def __init__(self, model, step_fn=None, warmup=2):
-        self.model = model
-        self.step_fn = step_fn or self._default_step
-        self.warmup = warmup
-        self.graph = None
+    """Captured training step.  world_size == 1: one graph for the whole step.  Data parallel: the model's
+    ``step_phases()`` are captured as separate graphs and the RCCL gradient reductions run between them on the same
+    stream (collectives are never captured)."""
 
-    def _default_step(self):
+    def __init__(self, model, warmup=2):
+        self.model = model
+        self.warmup = warmup
+        self.graphs = None
+        self.phases = None
+
+    def _eager_step(self):
         m = self.model
         if "check_collapse" in m.optimize_params.__code__.co_varnames:
             m.optimize_params(check_collapse=False)
@@ -30,20 +34,41 @@ class GraphedStep:
     def capture(self):
         """Run `warmup` eager steps on a side stream (allocator / autograd warm-up), then capture one step.
         Capturing only RECORDS the step (its kernels do not run): training state advances by `warmup` steps."""
+        from . import dist as vdist
         if self.warmup < 1:
             raise ValueError("at least one warm-up step on the side stream is required before capture")
         if F._TIMER[0] is not None:
             raise RuntimeError("kernel timing events cannot be recorded inside a graph capture")
+        m = self.model
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self.warmup):
-                self.step_fn()
+                self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.step_fn()
+        if vdist.world_size() > 1:
+            if not hasattr(m, "step_phases"):
+                raise NotImplementedError("%s has no step_phases() for data-parallel graph capture" % type(m).__name__)
+            self.phases = m.step_phases()
+        else:
+            self.phases = [(self._eager_step, None)]
+        reducers = [r for _, r in self.phases if r is not None]
+        for r in reducers:
+            r.suspended = True         # no collective may be issued while a capture is open
+        self.graphs = []
+        pool = None
+        try:
+            for fn, _ in self.phases:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool
+                self.graphs.append(g)
+        finally:
+            for r in reducers:
+                r.suspended = False
+                r.reset()
         torch.cuda.synchronize()
         return self
 
@@ -59,8 +84,10 @@ class GraphedStep:
                 setattr(m, k, o)
 
     def replay(self):
-        self.graph.replay()
+        for g, (_, red) in zip(self.graphs, self.phases):
+            g.replay()
+            if red is not None:
+                red.reduce_all()
         m = self.model
-        if hasattr(m, "reinit_d") and hasattr(m, "err_d") and m.__class__.__name__ == "Ganomaly":
-            if m.err_d.item() < 1e-5:          # reference models/ganomaly.py:519 (host decision, outside the graph)
-                m.reinit_d()
+        if type(m).__name__ == "Ganomaly" and m.err_d.item() < 1e-5:
+            m.reinit_d()                   # reference models/ganomaly.py:519 (host decision, outside the graph)

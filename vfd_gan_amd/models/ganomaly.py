@@ -224,7 +224,7 @@ class Ganomaly(GANBaseModel):
         self.pred_real, self.feat_real = self.netd(self.x)
         self.pred_fake, self.feat_fake = self.netd(self.fake.detach())
 
-    def backward_g(self):
+    def backward_g(self, join=True):
         # The reference lets this backward also deposit gradients into netD's parameters and then discards them
         # (optimizer_d.zero_grad() at :515 runs before they are ever used).  Freezing netD here skips exactly that
         # discarded filter-gradient work; everything that survives the step is unchanged.
@@ -243,19 +243,46 @@ class Ganomaly(GANBaseModel):
             for p in self.netd.parameters():
                 p.requires_grad_(True)
             self.reducer_d.enabled = True
-        self.reducer_g.finish()
+        if join:
+            self.reducer_g.finish()
 
-    def backward_d(self):
+    def backward_d(self, join=True):
         self.err_d_real = self.l_bce(self.pred_real, self.real_label)
         self.err_d_fake = self.l_bce(self.pred_fake, self.fake_label)
         self.err_d = (self.err_d_real + self.err_d_fake) * 0.5
         self.err_d.backward()
-        self.reducer_d.finish()
+        if join:
+            self.reducer_d.finish()
 
     def reinit_d(self):
         self.netd.apply(weights_init_dcgan)
         if self.rank == 0:
             print('   Reloading net d')
+
+    def step_phases(self):
+        """The step as three collective-free phases and the gradient reductions between them, for hipGraph capture
+        under data parallelism (vfd_gan_amd.graph.GraphedStep): [(phase, reducer to run after it or None), ...]."""
+        def a():
+            self.forward_g()
+            self.forward_d()
+            self.optimizer_g.zero_grad()
+            self.backward_g(join=False)
+
+        def b():
+            self.optimizer_g.step()
+            self.optimizer_d.zero_grad()
+            self.backward_d(join=False)
+
+        def c():
+            self.optimizer_d.step()
+            self._publish_errors()
+        return [(a, self.reducer_g), (b, self.reducer_d), (c, None)]
+
+    def _publish_errors(self):
+        self.errors_dict.update({'g/err_g/train': self.err_g, 'g/err_g_adv/train': self.err_g_adv,
+                                 'g/err_g_con/train': self.err_g_con, 'g/err_g_enc/train': self.err_g_enc,
+                                 'd/err_d/train': self.err_d, 'd/err_d_real/train': self.err_d_real,
+                                 'd/err_d_fake/train': self.err_d_fake})
 
     def optimize_params(self, check_collapse=True):
         self.forward_g()
@@ -269,9 +296,6 @@ class Ganomaly(GANBaseModel):
         self.backward_d()
         self.optimizer_d.step()
 
-        self.errors_dict.update({'g/err_g/train': self.err_g, 'g/err_g_adv/train': self.err_g_adv,
-                                 'g/err_g_con/train': self.err_g_con, 'g/err_g_enc/train': self.err_g_enc,
-                                 'd/err_d/train': self.err_d, 'd/err_d_real/train': self.err_d_real,
-                                 'd/err_d_fake/train': self.err_d_fake})
+        self._publish_errors()
         if check_collapse and self.err_d.item() < 1e-5:   # reference :519 (one host sync per step, as there)
             self.reinit_d()
