@@ -139,10 +139,12 @@ int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, c
                        const float* rstd, const float* gamma, const float* beta, int act, float slope,
                        void* stream);
 /* Backward: g = dy*act'(.), dgamma = sum g*xhat, dbeta = sum g,
- * dx = gamma*rstd*(g - dbeta/rows - xhat*dgamma/rows).  dgamma/dbeta are OVERWRITTEN.                     */
+ * dx = gamma*rstd*(g - dbeta/rows - xhat*dgamma/rows).  dgamma/dbeta (scratch, [C]) are OVERWRITTEN;
+ * dgamma_acc/dbeta_acc (NULL or the parameters' gradient buffers) are ACCUMULATED into.                   */
 int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C,
                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                        float slope, float* dgamma, float* dbeta, void* ws, void* stream);
+                        float slope, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* ws,
+                        void* stream);
 
 /* Element-wise activation and its backward from the OUTPUT (all supported activations are invertible in
  * sign / expressible from y): dx = dy * act'(y).                                                          */

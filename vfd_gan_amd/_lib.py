@@ -47,7 +47,7 @@ SIGNATURES = {
     "vfd_bn_stats_from_sums": (c_int, [c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_bn_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
-                                    c_vp, c_vp, c_vp, c_vp]),
+                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp]),
     "vfd_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp]),
     "vfd_avgpool_forward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 8 + [c_vp]),

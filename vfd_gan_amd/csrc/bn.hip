@@ -29,7 +29,7 @@ static Tiling make_tiling(long long rows, int C, int max_gy) {
   t.rows_per_block = (rows + gy - 1) / gy;
   return t;
 }
-constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_MAX_BLOCKS = 1024;  // partial workgroups per reduction
 
 // ---- statistics: per-workgroup (count, mean, M2) per channel ----------------------------------------------
 template <typename T>
@@ -250,24 +250,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
   }
 }
 
+// 8 channels x 32 part-lanes per workgroup: a lane folds every 32nd partial, 5 shuffles fold the lanes (fixed order).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* dgamma,
-                                                              float* dbeta) {
+                                                              float* dbeta, float* dgamma_acc, float* dbeta_acc) {
   const int Cp = (C + 7) & ~7;
-  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int pl = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
   double sg = 0, sgx = 0;
   if (c < C)
-    for (int j = pl; j < nparts; j += 8) {
+    for (int j = pl; j < nparts; j += 32) {
       sg += part[(size_t)j * 2 * Cp + c];
       sgx += part[(size_t)j * 2 * Cp + Cp + c];
     }
-  __shared__ double sh[2][8][32];
-  sh[0][pl][cl] = sg; sh[1][pl][cl] = sgx;
-  __syncthreads();
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    sg += __shfl_xor(sg, o, 64);
+    sgx += __shfl_xor(sgx, o, 64);
+  }
   if (pl == 0 && c < C) {
-    for (int j = 1; j < 8; ++j) { sg += sh[0][j][cl]; sgx += sh[1][j][cl]; }
     dbeta[c] = (float)sg;
     dgamma[c] = (float)sgx;
+    if (dbeta_acc != nullptr) dbeta_acc[c] += (float)sg;       // parameter-gradient arena (one writer per channel)
+    if (dgamma_acc != nullptr) dgamma_acc[c] += (float)sgx;
   }
 }
 
@@ -359,7 +363,7 @@ extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t row
 
 extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta, int act, float slope, float* dgamma,
-                                   float* dbeta, void* ws, void* stream) {
+                                   float* dbeta, float* dgamma_acc, float* dbeta_acc, void* ws, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_backward: bad dtype");
   VFD_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && ws && rows > 0 && C > 0, "bn_act_backward: bad arguments");
   const Tiling t = make_tiling(rows, C, BN_MAX_BLOCKS);
@@ -371,7 +375,7 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
   else
     hipLaunchKernelGGL(bn_act_bwd_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
   VFD_CHECK_LAUNCH("bn_act_bwd_partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, t.gy, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, part, t.gy, C, dgamma, dbeta, dgamma_acc, dbeta_acc);
   VFD_CHECK_LAUNCH("bn_bwd_finalize");
   const Tiling ta = make_tiling(rows, C, 8192);
   dim3 grid2(ta.gx, ta.gy);

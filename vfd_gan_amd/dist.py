@@ -92,6 +92,8 @@ class GradReducer:
         self.suspended = False   # set while a hipGraph capture is open: no collective may be issued then
         self._hooks = []
         for i, p in enumerate(self.params):
+            # fires once per backward after the parameter's LAST gradient contribution — also when the backward kernels
+            # accumulated in place and handed autograd None (functional._direct_grad)
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
 

@@ -194,6 +194,16 @@ def flatten(x):
     return ClTensor(_Reshape.apply(x.t, x.C, (d, h, w), False), x.C * d * h * w, 0)
 
 
+def _direct_grad(param):
+    """Parameters owned by vfd_gan_amd.optim.Adam carry a gradient that is a view into the optimiser's flat arena
+    (zeroed by zero_grad).  Backward kernels then ACCUMULATE straight into it (no separate gradient tensor, no
+    autograd `+=` pass) and return None to autograd.  The leaf's AccumulateGrad node still runs once per backward,
+    after its last contribution, so post-accumulate hooks (the data-parallel reducer's) keep firing at the right time."""
+    if param is not None and getattr(param, "_vfd_direct_grad", False) and param.grad is not None:
+        return param.grad
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # convolution family
 # ---------------------------------------------------------------------------------------------------------
@@ -350,6 +360,7 @@ class _Conv(torch.autograd.Function):
         ctx.geom = geom
         ctx.in_dhw = in_dhw
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
         return out
 
@@ -393,11 +404,20 @@ class _Conv(torch.autograd.Function):
                 e1.record()
                 timer.records.append(("conv_wgrad<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"), _conv_flops(desc), e0, e1,
                                       _geom_str(desc)))
-            gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-            check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
+            direct = _direct_grad(weight)
+            if direct is not None:
+                check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
+            else:
+                gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
-            check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, stream()), "bias_grad")
+            bias = ctx.bias_param
+            direct = _direct_grad(bias)
+            if direct is not None:
+                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), direct.data_ptr(), rows_out, Cout, 1.0, stream()), "bias_grad")
+            else:
+                gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
+                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, stream()), "bias_grad")
         return gx, gw, gb, None, None
 
 
@@ -474,11 +494,13 @@ class _BnAct(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+        dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
+        db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
         check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                       mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
-                                      dbeta.data_ptr(), ws.data_ptr(), stream()), "bn_act_backward")
-        return (dx, dgamma if gamma is not None else None, dbeta if beta is not None else None, None, None, None, None,
-                None, None, None, None)
+                                      dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ws.data_ptr(), stream()), "bn_act_backward")
+        return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
+                dbeta if (beta is not None and db_acc is None) else None, None, None, None, None, None, None, None, None)
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,

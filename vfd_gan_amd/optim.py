@@ -44,6 +44,7 @@ class Adam(torch.optim.Optimizer):
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad_arena[o:o + n].view(p.shape)
+                p._vfd_direct_grad = True    # backward kernels accumulate straight into the arena (functional._direct_grad)
         self._step = 0
         self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side counter (graph replay)
         self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
