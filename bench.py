@@ -76,8 +76,8 @@ def host_cores():
     return min(n, int(os.environ.get("VFD_CPU_BASELINE_CORES", "16")))
 
 
-def cpu_baseline(isize, nfr, steps=2):
-    """The oracle step on the host cores, bounded sample: 1 clip (nfr frames), 1 warm-up + `steps` timed steps."""
+def cpu_baseline(isize, nfr, steps=3, clips=16):
+    """The oracle step on the host cores, bounded sample (~10-20 s): `clips` clips, 1 warm-up + `steps` timed steps."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from vfd_oracle import ganomaly as OG
     from vfd_gan_amd.lib.data import synthetic_batch
@@ -87,15 +87,15 @@ def cpu_baseline(isize, nfr, steps=2):
     opt = OG.make_opt(isize=isize)
     og, od = OG.NetG(opt), OG.NetD(opt)
     opt_g, opt_d = OG.make_optimizers(og, od, opt)
-    x = OG.fold_frames(synthetic_batch(1, nfr, isize, 3, seed=1234)[0])
+    x = OG.fold_frames(synthetic_batch(clips, nfr, isize, 3, seed=1234)[0])
     OG.step(og, od, opt_g, opt_d, x, opt)
     t0 = time.perf_counter()
     for _ in range(steps):
         OG.step(og, od, opt_g, opt_d, x, opt)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle ganomaly step, 1 clip = %d frames %dx%d f32, 1 warm-up + %d timed steps (%.2f s/step)"
-                      % (nfr, isize, isize, steps, dt)}
+    return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle ganomaly step (stock torch.nn f32 on the host cores), %d clips = %d frames %dx%d, 1 warm-up + %d "
+                      "timed steps (%.2f s/step)" % (clips, clips * nfr, isize, isize, steps, dt)}
 
 
 def main():
@@ -204,8 +204,12 @@ def main():
             name, d = dom
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3
+            traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # runs folded by tools/pmc_traffic.py)
+            if a.dtype == "bf16" and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(tf / peak, 4), "traffic": None,
+                               "frac": round(tf / peak, 4), "traffic": traffic,
                                "launches_per_step": d["launches"] // timer_steps,
                                "timed_in": ("eager pass after the timed region" if use_graph else "timed region"),
                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),

@@ -49,7 +49,20 @@ struct DimClass {  // per-dimension description of the taps of one output class
   int so;   // output coordinate multiplier of q
   int r;    // output coordinate offset
   int Q;    // number of q along this dim
+  FastDiv fq;  // division by Q (pixel index decomposition)
 };
+
+// device-side construction of the magic number (a handful of scalar instructions per workgroup, classes differ per block)
+__device__ __forceinline__ FastDiv dev_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  const uint32_t l = (d > 1) ? 32 - __builtin_clz(d - 1) : 0;   // ceil(log2 d)
+  const uint32_t p = 31 + l;
+  f.magic = (uint32_t)(((1ull << p) + d - 1) / d);
+  f.shift = p;
+  f.d = d;
+  return f;
+}
 
 __device__ __forceinline__ DimClass make_dim(int transposed, int r, int k, int s, int p, int O) {
   DimClass d;
@@ -66,6 +79,7 @@ __device__ __forceinline__ DimClass make_dim(int transposed, int r, int k, int s
     d.r = r;
     d.Q = (O > r) ? (O - r + s - 1) / s : 0;
   }
+  d.fq = dev_fastdiv((uint32_t)d.Q);
   return d;
 }
 
@@ -222,14 +236,14 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     const int g = wave + NWAVES * i;
     const long long m = m0 + g * RPI + lrow;
     if (g < NP && m < Mcls) {
-      unsigned q = (unsigned)m;            // M < 2^31 (checked on the host): 32-bit divisions
-      const int qw = (int)(q % (unsigned)dw.Q); q /= (unsigned)dw.Q;
-      const int qh = (int)(q % (unsigned)dh.Q); q /= (unsigned)dh.Q;
-      const int qd = (int)(q % (unsigned)dd.Q); q /= (unsigned)dd.Q;
+      uint32_t q = (uint32_t)m, qw, qh, qd;     // M < 2^31 (checked on the host): multiply-shift divisions
+      fdivmod(q, dw.fq, q, qw);
+      fdivmod(q, dh.fq, q, qh);
+      fdivmod(q, dd.fq, q, qd);
       pn[i] = (int)q;
-      pid[i] = qd * dd.a + dd.c0;
-      pih[i] = qh * dh.a + dh.c0;
-      piw[i] = qw * dw.a + dw.c0;
+      pid[i] = (int)qd * dd.a + dd.c0;
+      pih[i] = (int)qh * dh.a + dh.c0;
+      piw[i] = (int)qw * dw.a + dw.c0;
     } else {
       pn[i] = -1; pid[i] = 0; pih[i] = 0; piw[i] = 0;
     }
@@ -348,12 +362,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
     opix[j] = -1;
     if (m < Mcls) {
-      unsigned q = (unsigned)m;
-      const int qw = (int)(q % (unsigned)dw.Q); q /= (unsigned)dw.Q;
-      const int qh = (int)(q % (unsigned)dh.Q); q /= (unsigned)dh.Q;
-      const int qd = (int)(q % (unsigned)dd.Q); q /= (unsigned)dd.Q;
+      uint32_t q = (uint32_t)m, qw, qh, qd;
+      fdivmod(q, dw.fq, q, qw);
+      fdivmod(q, dh.fq, q, qh);
+      fdivmod(q, dd.fq, q, qd);
       const int n = (int)q;
-      opix[j] = ((((long long)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r)) * p.Cop;
+      opix[j] = ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
     }
   }
   const bool want_stats = p.stats != nullptr;
