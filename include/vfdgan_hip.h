@@ -118,7 +118,8 @@ int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes);
 int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
                    void* stream);
 int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream);
-int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* stream);
+size_t vfd_bias_grad_workspace(int C);
+int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (training mode) fused with the activation that follows it.

@@ -257,31 +257,49 @@ __global__ void dropout_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx,
 }
 
 // ---- bias gradient: db[c] = beta*db[c] + sum_rows dy[row][c] --------------------------------------------------
-// grid.x = granule, one workgroup per granule; threads stride over rows, LDS tree at the end (deterministic).
+// Two-stage column sum (deterministic): workgroups of TX granule-lanes x TY row-lanes write per-workgroup partials,
+// a finalize kernel (8 channels x 32 lanes) folds them.
 template <typename T>
-__global__ void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, long long rows, int C, float beta) {
-  const int Cp = (C + 7) & ~7;
-  const int g = blockIdx.x;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ dy, float* __restrict__ part, long long rows,
+                                                             int C, int TX, long long rpb) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long long r = threadIdx.x; r < rows; r += blockDim.x) {
-    float v[8];
-    load8(dy + r * Cp + g * 8, v);
+  if (g < GR) {
+    const long long rbeg = (long long)blockIdx.y * rpb;
+    long long rend = rbeg + rpb;
+    if (rend > rows) rend = rows;
+    for (long long r = rbeg + ty; r < rend; r += TY) {
+      float v[8];
+      load8(dy + r * Cp + g * 8, v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[k] += v[k];
+      for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
   }
-  __shared__ float red[8][EW_THREADS / 64];
+  __shared__ float sh[256][8 + 1];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float t = wave_sum(s[k]);
-    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = t;
-  }
+  for (int k = 0; k < 8; ++k) sh[threadIdx.x][k] = s[k];
   __syncthreads();
-  if (threadIdx.x < 8) {
-    const int c = g * 8 + threadIdx.x;
-    float t = 0.f;
-    for (int w = 0; w < EW_THREADS / 64; ++w) t += red[threadIdx.x][w];
-    if (c < C) db[c] = (beta != 0.f) ? beta * db[c] + t : t;
+  if (ty == 0 && g < GR) {
+    for (int j = 1; j < TY; ++j)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += sh[j * TX + tx][k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[(size_t)blockIdx.y * Cp + g * 8 + k] = s[k];
   }
+}
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* db,
+                                                              float beta) {
+  const int Cp = (C + 7) & ~7;
+  const int pl = threadIdx.x & 31;
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
+  double s = 0;
+  if (c < C)
+    for (int j = pl; j < nparts; j += 32) s += part[(size_t)j * Cp + c];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (pl == 0 && c < C) db[c] = (beta != 0.f) ? beta * db[c] + (float)s : (float)s;
 }
 
 // ---- Adam -----------------------------------------------------------------------------------------------------
@@ -477,15 +495,30 @@ extern "C" int vfd_dropout_backward(int dtype, const void* dy, void* dx, const u
   return VFD_OK;
 }
 
-extern "C" int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* stream) {
+constexpr int COLSUM_MAX_PARTS = 1024;
+extern "C" size_t vfd_bias_grad_workspace(int C) { return (size_t)COLSUM_MAX_PARTS * cpad(C) * sizeof(float); }
+
+extern "C" int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* ws, void* stream) {
   CHECK_DTYPE(dtype, "bias_grad");
-  VFD_REQUIRE(dy && db && rows > 0 && C > 0, "bias_grad: bad arguments");
-  const unsigned grid = (unsigned)(cpad(C) >> 3);
+  VFD_REQUIRE(dy && db && ws && rows > 0 && C > 0, "bias_grad: bad arguments");
+  const int GR = cpad(C) >> 3;
+  int tx = 1;
+  while (tx < GR && tx < 256) tx <<= 1;
+  const int ty = 256 / tx, gx = (GR + tx - 1) / tx;
+  long long gy = (rows + (long long)ty * 8 - 1) / ((long long)ty * 8);
+  const long long cap = COLSUM_MAX_PARTS / gx > 0 ? COLSUM_MAX_PARTS / gx : 1;
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  const long long rpb = (rows + gy - 1) / gy;
+  float* part = reinterpret_cast<float*>(ws);
+  dim3 grid(gx, (unsigned)gy);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)dy, db, (long long)rows, C, beta);
+    hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy, part, (long long)rows, C, tx, rpb);
   else
-    hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(grid), dim3(EW_THREADS), 0, as_stream(stream), (const float*)dy, db, (long long)rows, C, beta);
-  VFD_CHECK_LAUNCH("bias_grad");
+    hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)dy, part, (long long)rows, C, tx, rpb);
+  VFD_CHECK_LAUNCH("colsum_partial");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, as_stream(stream), part, (int)gy, C, db, beta);
+  VFD_CHECK_LAUNCH("colsum_finalize");
   return VFD_OK;
 }
 

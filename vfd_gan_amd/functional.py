@@ -413,11 +413,14 @@ class _Conv(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             bias = ctx.bias_param
             direct = _direct_grad(bias)
+            bws = torch.empty(lib.vfd_bias_grad_workspace(Cout), dtype=torch.uint8, device=x.device)
             if direct is not None:
-                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), direct.data_ptr(), rows_out, Cout, 1.0, stream()), "bias_grad")
+                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), direct.data_ptr(), rows_out, Cout, 1.0, bws.data_ptr(),
+                                        stream()), "bias_grad")
             else:
                 gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
-                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, stream()), "bias_grad")
+                check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, bws.data_ptr(),
+                                        stream()), "bias_grad")
         return gx, gw, gb, None, None
 
 
