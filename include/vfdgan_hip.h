@@ -174,10 +174,12 @@ int vfd_split_channels(int dtype, const void* src, void* a, void* b, int64_t row
                        void* stream);
 /* dst[rows][CPAD(reps)] = src[rows][CPAD(1)] channel 0 broadcast to `reps` channels (gray2rgb).            */
 int vfd_broadcast_channel(int dtype, const void* src, void* dst, int64_t rows, int reps, void* stream);
-/* y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based generator keyed by (seed, element).
- * mask (uint8 [n]) is written for the backward; pass mask_in != NULL to impose a mask (parity tests).     */
+/* y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based generator keyed by (seed, *step_dev, element).
+ * mask (uint8 [n]) is written for the backward; pass mask_in != NULL to impose a mask (parity tests).
+ * step_dev (NULL or a device int64 the caller increments once per training step) keeps the masks changing when a
+ * captured hipGraph of the step is replayed with a constant `seed` argument.                              */
 int vfd_dropout_forward(int dtype, const void* x, void* y, uint8_t* mask_out, const uint8_t* mask_in,
-                        int64_t n, float p, uint64_t seed, void* stream);
+                        int64_t n, float p, uint64_t seed, const int64_t* step_dev, void* stream);
 int vfd_dropout_backward(int dtype, const void* dy, void* dx, const uint8_t* mask, int64_t n, float p,
                          void* stream);
 

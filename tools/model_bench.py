@@ -22,6 +22,7 @@ ap.add_argument("--nfr", type=int, default=16)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--layers", action="store_true")
+ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of the step")
 a = ap.parse_args()
 F.set_compute_dtype(a.dtype)
 args = types.SimpleNamespace(batchsize=a.batch, nfr=a.nfr, isize=a.isize, ich=3, lr=2e-5, beta1=0.5, w_adv=1, w_con=10, pos_weight=2,
@@ -34,6 +35,21 @@ else:
     from vfd_gan_amd.models.ganomaly import Ganomaly as M
 m = M(args, None)
 m.set_input(synthetic_batch(a.batch, a.nfr, a.isize, 3, seed=1))
+if a.graph:
+    from vfd_gan_amd.graph import GraphedStep
+    step = GraphedStep(m, warmup=2).capture()
+    for _ in range(2):
+        step.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print("%s %dx%dx%d batch %d %s [hipGraph]: %.1f ms/step = %.1f clips/s ; peak mem %.1f GB ; losses %s" % (
+        a.model, a.nfr, a.isize, a.isize, a.batch, a.dtype, dt * 1e3, a.batch / dt, torch.cuda.max_memory_allocated() / 2 ** 30,
+        {k: round(v, 4) for k, v in m.errors().items()}))
+    sys.exit(0)
 for _ in range(2):
     m.optimize_params()
 torch.cuda.synchronize()

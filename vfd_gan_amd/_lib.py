@@ -58,7 +58,7 @@ SIGNATURES = {
     "vfd_concat_channels": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "vfd_split_channels": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "vfd_broadcast_channel": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
-    "vfd_dropout_forward": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_u64, c_vp]),
+    "vfd_dropout_forward": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_u64, c_vp, c_vp]),
     "vfd_dropout_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "vfd_loss_workspace": (c_sz, [c_i64, c_int]),
     "vfd_loss_forward": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_i64, c_int, c_f32, c_vp, c_vp]),

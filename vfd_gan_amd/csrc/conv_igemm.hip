@@ -459,7 +459,8 @@ __global__ void conv_splitk_finish_kernel(const float* __restrict__ ws, T* __res
 
 template <int TILE_C, int TILE_P>
 int pick_ksplit(const ConvP& p, long long M, int bk) {
-  if (p.transposed || p.stats != nullptr) return 1;
+  // regular convolutions, and transposed ones with unit stride (one output class, out pixel == m)
+  if ((p.transposed && p.sd * p.sh * p.sw != 1) || p.stats != nullptr) return 1;
   const long long blocks = ((M + TILE_P - 1) / TILE_P) * ((p.Cout + TILE_C - 1) / TILE_C);
   const int nsteps = (p.Kw + bk - 1) / bk;
   if (blocks >= 128 || nsteps < 32) return 1;

@@ -214,7 +214,9 @@ __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
 }
 template <typename T>
 __global__ void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ mout,
-                                   const uint8_t* __restrict__ min, long long n8, float p, uint64_t seed) {
+                                   const uint8_t* __restrict__ min, long long n8, float p, uint64_t seed,
+                                   const long long* __restrict__ step_dev) {
+  if (step_dev != nullptr) seed += 0xD1B54A32D192ED03ull * (uint64_t)(*step_dev);   // device-side step counter (graph replay)
   const float scale = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
@@ -470,15 +472,15 @@ extern "C" int vfd_broadcast_channel(int dtype, const void* src, void* dst, int6
 }
 
 extern "C" int vfd_dropout_forward(int dtype, const void* x, void* y, uint8_t* mask_out, const uint8_t* mask_in, int64_t n,
-                                   float p, uint64_t seed, void* stream) {
+                                   float p, uint64_t seed, const int64_t* step_dev, void* stream) {
   CHECK_DTYPE(dtype, "dropout_forward");
   VFD_REQUIRE(x && y && n > 0 && (n & 7) == 0, "dropout_forward: n must be a positive multiple of 8");
   VFD_REQUIRE(p >= 0.f && p < 1.f, "dropout_forward: p must be in [0,1)");
   const long long n8 = n >> 3;
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, mask_out, mask_in, n8, p, seed);
+    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, mask_out, mask_in, n8, p, seed, (const long long*)step_dev);
   else
-    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, mask_out, mask_in, n8, p, seed);
+    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, mask_out, mask_in, n8, p, seed, (const long long*)step_dev);
   VFD_CHECK_LAUNCH("dropout_forward");
   return VFD_OK;
 }

@@ -644,13 +644,13 @@ def gray2rgb(x):
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed, mask_in):
+    def forward(ctx, x, p, seed, mask_in, step_dev):
         x = x.contiguous()
         n = x.numel()
         y = torch.empty_like(x)
         mask = torch.empty(n, dtype=torch.uint8, device=x.device)
         check(load().vfd_dropout_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), mask.data_ptr(), ptr(mask_in), n, p,
-                                         seed, stream()), "dropout_forward")
+                                         seed, ptr(step_dev), stream()), "dropout_forward")
         ctx.p = p
         ctx.save_for_backward(mask)
         return y
@@ -662,15 +662,26 @@ class _Dropout(torch.autograd.Function):
         dx = torch.empty_like(gy)
         check(load().vfd_dropout_backward(dtype_code(gy.dtype), gy.data_ptr(), dx.data_ptr(), mask.data_ptr(), gy.numel(),
                                           ctx.p, stream()), "dropout_backward")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "mask_provider": None}
+_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "mask_provider": None, "step_dev": None}
 
 
 def dropout_manual_seed(seed):
     _DROPOUT_STATE["seed"] = int(seed)
     _DROPOUT_STATE["calls"] = 0
+
+
+def dropout_begin_step(device):
+    """Call once at the start of every training step: resets the per-step call index (so a step issues the same
+    host-side seeds every time — required for hipGraph replay) and advances the DEVICE step counter that the kernels
+    mix into the seed (so the masks still change from step to step, also under replay)."""
+    st = _DROPOUT_STATE
+    if st["step_dev"] is None or st["step_dev"].device != device:
+        st["step_dev"] = torch.zeros(1, dtype=torch.int64, device=device)
+    st["step_dev"].add_(1)
+    st["calls"] = 0
 
 
 def set_dropout_mask_provider(fn):
@@ -696,7 +707,7 @@ def dropout(x, p, training=True):
             mcl = to_cl(m, dtype=torch.float32).t
             mask_in = (mcl != 0).to(torch.uint8).contiguous().view(-1)
     seed = (st["seed"] * 0x9E3779B1 + idx * 0x85EBCA6B) & 0xFFFFFFFFFFFFFFFF
-    return ClTensor(_Dropout.apply(x.t, float(p), seed, mask_in), x.C, x.nsp)
+    return ClTensor(_Dropout.apply(x.t, float(p), seed, mask_in, st["step_dev"]), x.C, x.nsp)
 
 
 # ---------------------------------------------------------------------------------------------------------

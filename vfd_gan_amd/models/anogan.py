@@ -119,8 +119,7 @@ class AnoGAN(GANBaseModel):
         self.reducer_g = vdist.GradReducer.for_optimizer(self.g_opt)
         self.reducer_d = vdist.GradReducer.for_optimizer(self.d_opt)
         self.ones_label, self.zeros_label = 1.0, 0.0
-        self._zgen = torch.Generator(device=self.device)
-        self._zgen.manual_seed(4321 + 7919 * self.rank)     # per-rank noise streams
+        torch.cuda.manual_seed(4321 + 7919 * self.rank)     # per-rank noise streams
         self.z = None                                       # tests may impose the noise
 
     def set_input(self, data):
@@ -128,13 +127,15 @@ class AnoGAN(GANBaseModel):
         self.real_cl = F.to_cl(self.real)
 
     def optimize_params(self):
+        F.dropout_begin_step(self.device)
         # NetD  (reference :231-243)
         self.d_opt.zero_grad()
         dis_real = self.netd(self.real_cl)[0]
         dis_loss_real = self.loss(dis_real, self.ones_label)
         dis_loss_real.backward()
 
-        z = self.z if self.z is not None else torch.randn(self.args.batchsize, 100, device=self.device, generator=self._zgen)
+        # torch's default device generator is graph-safe (its Philox offset advances under hipGraph replay)
+        z = self.z if self.z is not None else torch.randn(self.args.batchsize, 100, device=self.device)
         gen_fake = self.netg(F.to_cl(z))
         dis_fake = self.netd(gen_fake.detach())[0]
         dis_loss_fake = self.loss(dis_fake, self.zeros_label)

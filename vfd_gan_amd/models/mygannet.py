@@ -245,6 +245,7 @@ class MyGAN(GANBaseModel):
         print('Reloading Net d')
 
     def optimize_params(self):
+        F.dropout_begin_step(self.device)
         self.netg.train()
         self.netd.train()
 
