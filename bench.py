@@ -134,15 +134,27 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
-            tdist.barrier()
+        vdist.barrier()
         torch.cuda.synchronize()
 
     use_graph = not a.no_graph
     timer = None
     if use_graph:
         from vfd_gan_amd.graph import GraphedStep
-        step = GraphedStep(model, warmup=max(a.warmup, 2)).capture()      # eager warm-up steps + one captured step
+        ok = 1
+        try:
+            step = GraphedStep(model, warmup=max(a.warmup, 2)).capture()      # eager warm-up steps + one captured step
+        except Exception as e:  # noqa: BLE001  (capture problems must not take the benchmark down)
+            ok = 0
+            print("rank %d: hipGraph capture failed (%s: %s) - falling back to eager launches" % (rank, type(e).__name__, e),
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+        if world > 1:      # every rank must take the same path, or their collectives no longer match
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            ok = int(flag.item())
+        use_graph = bool(ok)
+    if use_graph:
         run = step.replay
         for _ in range(a.warmup):
             run()
@@ -220,7 +232,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.isize, a.nfr)
         print(json.dumps(out), flush=True)
     if world > 1:
-        tdist.barrier()
+        vdist.barrier()
         tdist.destroy_process_group()
 
 

@@ -43,6 +43,44 @@ __global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
   }
 }
 
+// Large windows (the "global" pools of SDisc / TDisc: (nfr,1,1) and (1,isize,isize)): one workgroup per output
+// granule, threads stride over the window, fixed-order LDS tree (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_reduce_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W,
+                                                             int Cp, int kd, int kh, int kw) {
+  const int GR = Cp >> 3, Do = D / kd, Ho = H / kh, Wo = W / kw;
+  long long q = blockIdx.x;
+  const int g = (int)(q % GR); q /= GR;
+  const int ow = (int)(q % Wo); q /= Wo;
+  const int oh = (int)(q % Ho); q /= Ho;
+  const int od = (int)(q % Do); q /= Do;
+  const int n = (int)q;
+  const int win = kd * kh * kw;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = threadIdx.x; t < win; t += 256) {
+    const int c = t % kw, b = (t / kw) % kh, a = t / (kw * kh);
+    const size_t pix = ((size_t)(n * D + od * kd + a) * H + oh * kh + b) * W + ow * kw + c;
+    float v[8];
+    load8(x + pix * Cp + g * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += v[k];
+  }
+  __shared__ float sh[8][4];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float inv = 1.f / (float)win;
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (((sh[k][0] + sh[k][1]) + sh[k][2]) + sh[k][3]) * inv;
+    store8(y + (size_t)blockIdx.x * 8, o);
+  }
+}
+
 template <typename T>
 __global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int D, int H, int W, int Cp, int kd, int kh,
                                    int kw) {
@@ -170,6 +208,14 @@ extern "C" int vfd_avgpool_forward(int dtype, const void* x, void* y, int N, int
   VFD_REQUIRE(x && y && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "avgpool_forward: bad kernel");
   const int Cp = cpad(C);
   const long long total = (long long)N * (D / kd) * (H / kh) * (W / kw) * (Cp >> 3);
+  if (kd * kh * kw >= 256 && total < 0x7fffffffLL) {     // global pools: few outputs, huge windows
+    if (dtype == VFD_BF16)
+      hipLaunchKernelGGL(avgpool_reduce_kernel<bf16_t>, dim3((unsigned)total), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, N, D, H, W, Cp, kd, kh, kw);
+    else
+      hipLaunchKernelGGL(avgpool_reduce_kernel<float>, dim3((unsigned)total), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, N, D, H, W, Cp, kd, kh, kw);
+    VFD_CHECK_LAUNCH("avgpool_reduce");
+    return VFD_OK;
+  }
   if (dtype == VFD_BF16)
     hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, N, D, H, W, Cp, kd, kh, kw);
   else

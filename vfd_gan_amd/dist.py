@@ -38,11 +38,20 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_PORT", "29500")
     use_gpu = torch.cuda.is_available()
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+        backend = os.environ.get("VFD_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
     if use_gpu:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     tdist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
     return rank(), world_size()
+
+
+def barrier():
+    """Process-group barrier bound to this rank's device (RCCL wants the device named; gloo does not take one)."""
+    if world_size() > 1:
+        if tdist.get_backend() == "nccl" and torch.cuda.is_available():
+            tdist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            tdist.barrier()
 
 
 def broadcast_module(module, src=0):

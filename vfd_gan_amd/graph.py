@@ -89,5 +89,5 @@ class GraphedStep:
             if red is not None:
                 red.reduce_all()
         m = self.model
-        if type(m).__name__ == "Ganomaly" and m.err_d.item() < 1e-5:
+        if hasattr(m, "d_collapsed") and m.d_collapsed():
             m.reinit_d()                   # reference models/ganomaly.py:519 (host decision, outside the graph)

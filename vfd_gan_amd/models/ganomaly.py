@@ -255,9 +255,22 @@ class Ganomaly(GANBaseModel):
             self.reducer_d.finish()
 
     def reinit_d(self):
+        """Reference :496-500: re-apply the initialiser to netD.  Replicas must stay identical, so rank 0's new
+        weights are broadcast."""
         self.netd.apply(weights_init_dcgan)
+        vdist.broadcast_module(self.netd)
+        F.invalidate_weight_cache()
         if self.rank == 0:
             print('   Reloading net d')
+
+    def d_collapsed(self):
+        """Reference :519 `err_d.item() < 1e-5` — the step's one host sync.  Under data parallelism the decision is
+        taken on the rank-averaged loss so that every replica takes the same branch."""
+        e = self.err_d.detach().clone()
+        if self.world_size > 1:
+            torch.distributed.all_reduce(e)
+            e = e / self.world_size
+        return e.item() < 1e-5
 
     def step_phases(self):
         """The step as three collective-free phases and the gradient reductions between them, for hipGraph capture
@@ -297,5 +310,5 @@ class Ganomaly(GANBaseModel):
         self.optimizer_d.step()
 
         self._publish_errors()
-        if check_collapse and self.err_d.item() < 1e-5:   # reference :519 (one host sync per step, as there)
+        if check_collapse and self.d_collapsed():   # reference :519 (one host sync per step, as there)
             self.reinit_d()
