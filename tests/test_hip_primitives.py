@@ -32,6 +32,14 @@ CONV_CASES = [
     ("K6_convT2d_k4s2", (2, 24, 7, 7), 12, 4, 2, 1, 0, True, False),
     ("K6_convT2d_to3", (2, 16, 8, 8), 3, 4, 2, 1, 0, True, False),
     ("K6_conv2d_extra_k3", (2, 16, 8, 8), 16, 3, 1, 1, 0, False, False),
+    # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients
+    ("K6_conv2d_first_3to64", (3, 3, 20, 14), 64, 4, 2, 1, 0, False, True),
+    ("K6_conv2d_first_3to40", (2, 3, 18, 22), 40, 4, 2, 1, 0, False, False),
+    ("K1_conv3d_first_3to32", (2, 3, 6, 10, 10), 32, 4, 2, 1, 0, False, True),
+    ("K6_convT2d_last_64to3", (3, 64, 9, 7), 3, 4, 2, 1, 0, True, True),
+    ("K6_convT2d_last_32to1", (2, 32, 6, 6), 1, 4, 2, 1, 0, True, False),
+    ("K6_convT2d_last_128to4", (1, 128, 5, 9), 4, 4, 2, 1, 0, True, True),
+    ("K6_convT2d_last_64to3_tall", (1, 64, 37, 5), 3, 4, 2, 1, 0, True, False),
 ]
 
 

@@ -33,6 +33,10 @@ void vfd_set_error(const char* fmt, ...);
     }                                                                 \
   } while (0)
 
+// conv_small.hip: 1 = handled (or, with query, would be handled), 0 = not a thin-channel shape, < 0 = launch error
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, bool want_stats,
+                       bool query, hipStream_t st);
+
 static inline int cpad(int c) { return (c + 7) & ~7; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -1,0 +1,355 @@
+// Thin-channel ends of the image pyramids (bf16): the first convolution of an encoder / discriminator
+// (Conv(nc -> ndf, 4, 2, 1), nc <= 8; models/ganomaly.py:39-41, :155-160) and the last transposed convolution of a
+// decoder (ConvTranspose(ngf -> nc, 4, 2, 1), nc <= 4; models/ganomaly.py:100-104), together with the data gradients
+// that have the same two shapes.  In the implicit-GEMM kernel these layers run 4 (resp. 16) K-steps per workgroup and
+// are bound by the per-workgroup fill/drain of the LDS ring (conv_igemm.hip), 5-10x off the HBM time of their tensors.
+// Here neither operand is staged: the activation operand goes from global memory straight into MFMA B fragments
+// (a pixel's 8-channel granule, or 8 consecutive channels of a 64..128-channel pixel, IS a fragment lane's 16 bytes)
+// and the filter lives in LDS / registers for the whole kernel.
+//
+//   conv_cin8   regular conv, CPAD(Cin) == 8, kw == 4, kh == 4: one K-step = the 4 taps of one filter row
+//               (4 taps x 8 channels = 32 = K of v_mfma_f32_16x16x32_bf16).  Persistent workgroups, filter in LDS in
+//               fragment order, 64 channels x 32 pixels per wave.
+//   convt_thin  ConvTranspose k4 s2 p1 with Cout <= 4, scatter form: per INPUT pixel the 16 taps x Cout products
+//               D[tap, co] = W[:, co, tap] . x[pixel, :] are one small GEMM (16*Cout rows, K = Cin); the strip's D
+//               goes to LDS and every output pixel then adds its 4 contributing (input pixel, tap) terms in a fixed
+//               order (deterministic, unlike an atomic scatter).  The input is read once instead of once per tap.
+#include "common.hpp"
+#include <stdlib.h>
+
+namespace {
+
+// ============================================================================================================
+// conv_cin8
+// ============================================================================================================
+struct Cin8P {
+  const bf16_t* x;
+  const bf16_t* w;      // packed [Cout][kd*4*4][8]
+  bf16_t* y;
+  const float* bias;
+  int N, Di, Hi, Wi, Do, Ho, Wo, Cout, Cop;
+  int kd, sd, sh, sw, pd, ph, pw;
+  int act;
+  float slope;
+  FastDiv fWo, fHo, fDo;
+  long long M;          // output pixels
+  int ntiles;           // tiles of CIN8_TILE pixels
+};
+
+constexpr int CIN8_NI = 4;                 // 64 output channels per wave
+constexpr int CIN8_NJ = 2;                 // 32 pixels per wave
+constexpr int CIN8_WAVES = 4;
+constexpr int CIN8_TILE = CIN8_WAVES * CIN8_NJ * 16;   // 128 pixels per workgroup and tile
+
+__global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin8P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // filter fragments [kd*4][NI][64 lanes][16 B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;            // K group of the fragment = tap kx
+  const int nks = p.kd * 4;
+
+  // ---- filter -> LDS, in fragment order: lane (m = lane&15, g) of fragment (ks, i) holds w[i*16+m][ks*4+g][0..7]
+  for (int f = tid; f < nks * CIN8_NI * 64; f += 64 * CIN8_WAVES) {
+    const int l = f & 63, fi = (f >> 6) % CIN8_NI, ks = (f >> 6) / CIN8_NI;
+    const int co = fi * 16 + (l & 15), tap = ks * 4 + (l >> 4);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (co < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (nks * 4) + tap) * 8);
+    *reinterpret_cast<uint4*>(smem + (size_t)f * 16) = v;
+  }
+  __syncthreads();
+
+  const int cq = g * 4;
+  float b4[CIN8_NI][4];
+#pragma unroll
+  for (int i = 0; i < CIN8_NI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = i * 16 + cq + r;
+      b4[i][r] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+    }
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    long long base[CIN8_NJ];      // element offset of (n, id0, ih0, iw) — may point outside the block, only used when valid
+    int id0[CIN8_NJ], ih0[CIN8_NJ];
+    bool colok[CIN8_NJ];
+    long long mpix[CIN8_NJ];
+#pragma unroll
+    for (int j = 0; j < CIN8_NJ; ++j) {
+      const long long m = (long long)tile * CIN8_TILE + wave * (CIN8_NJ * 16) + j * 16 + (lane & 15);
+      mpix[j] = m < p.M ? m : -1;
+      uint32_t q = (uint32_t)(m < p.M ? m : 0), ow, oh, od;
+      fdivmod(q, p.fWo, q, ow);
+      fdivmod(q, p.fHo, q, oh);
+      fdivmod(q, p.fDo, q, od);
+      const int n = (int)q;
+      id0[j] = (int)od * p.sd - p.pd;
+      ih0[j] = (int)oh * p.sh - p.ph;
+      const int iw = (int)ow * p.sw - p.pw + g;
+      colok[j] = m < p.M && (unsigned)iw < (unsigned)p.Wi;
+      base[j] = ((((long long)n * p.Di + id0[j]) * p.Hi + ih0[j]) * p.Wi + iw) * 8;
+    }
+    f32x4 acc[CIN8_NI][CIN8_NJ];
+#pragma unroll
+    for (int i = 0; i < CIN8_NI; ++i)
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kz = 0; kz < p.kd; ++kz) {
+      // the 4 filter rows of this depth tap: 4 x NJ fragment loads in flight, every address in bounds (masked ones
+      // read the start of the block and are zeroed below: no branch, no early wait)
+      uint4 braw[4][CIN8_NJ];
+      bool bok[4][CIN8_NJ];
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int j = 0; j < CIN8_NJ; ++j) {
+          const bool ok = colok[j] && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
+          const long long off = ok ? base[j] + ((long long)kz * p.Hi + ky) * p.Wi * 8 : 0;
+          braw[ky][j] = *reinterpret_cast<const uint4*>(p.x + off);
+          bok[ky][j] = ok;
+        }
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky) {
+        const int ks = kz * 4 + ky;
+        bf16x8 a[CIN8_NI], b[CIN8_NJ];
+#pragma unroll
+        for (int i = 0; i < CIN8_NI; ++i)
+          a[i] = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(ks * CIN8_NI + i) * 64 + lane) * 16);
+#pragma unroll
+        for (int j = 0; j < CIN8_NJ; ++j) {
+          uint4 v = braw[ky][j];
+          if (!bok[ky][j]) v = make_uint4(0, 0, 0, 0);
+          b[j] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < CIN8_NI; ++i)
+#pragma unroll
+          for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: bias, activation, channels-last store (out pixel == m for a regular convolution)
+#pragma unroll
+    for (int j = 0; j < CIN8_NJ; ++j) {
+      if (mpix[j] < 0) continue;
+      bf16_t* dst = p.y + mpix[j] * p.Cop;
+#pragma unroll
+      for (int i = 0; i < CIN8_NI; ++i) {
+        const int c = i * 16 + cq;
+        if (c >= p.Cop) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (c + r < p.Cout) ? act_apply(acc[i][j][r] + b4[i][r], p.act, p.slope) : 0.f;
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst + c) = o;
+      }
+    }
+  }
+}
+
+// ============================================================================================================
+// convt_thin
+// ============================================================================================================
+struct ThinP {
+  const bf16_t* x;
+  const bf16_t* w;      // packed [Cout][16][Cip]
+  bf16_t* y;
+  const float* bias;
+  int planes, Hi, Wi, Ho, Wo, Cip, Cout, Cop;
+  int R, nstrips;       // input rows per strip (plus one halo row on either side)
+  int act;
+  float slope;
+  FastDiv fWo;
+};
+
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void convt_thin_kernel(const ThinP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // D[(R+2)*Wi pixels][16*Cout + 1] float
+  float* D = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;
+  const int plane = blockIdx.x / p.nstrips;
+  const int strip = blockIdx.x - plane * p.nstrips;
+  const int r0 = strip * p.R;
+  const int row_lo = max(r0 - 1, 0);
+  const int row_hi = min(r0 + p.R + 1, p.Hi);
+  const int npx = (row_hi - row_lo) * p.Wi;
+  const int ntile = (npx + 15) >> 4;
+  const int mrows = 16 * p.Cout;
+  const int stride = mrows + 1;      // odd: the pixel-strided accesses below spread over all banks
+
+  // filter fragments, resident in registers: row m = tap * Cout + co
+  bf16x8 a[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + (lane & 15);
+    const int tap = m / p.Cout, co = m - tap * p.Cout;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < mrows) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * 16 + tap) * p.Cip + ks * 32 + g * 8);
+      a[mt][ks] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  const bf16_t* xs = p.x + ((size_t)plane * p.Hi + row_lo) * p.Wi * p.Cip;
+  // ---- D = W^T x over the strip's pixels, 16 pixels per MFMA column tile, 2 tiles per wave and pass
+  for (int t0 = wave * 2; t0 < ntile; t0 += 8) {
+    uint4 braw[2][KS];
+    int px[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      px[u] = (t0 + u) * 16 + (lane & 15);
+      const int pc = px[u] < npx ? px[u] : 0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) braw[u][ks] = *reinterpret_cast<const uint4*>(xs + (size_t)pc * p.Cip + ks * 32 + g * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 b = __builtin_bit_cast(bf16x8, braw[u][ks]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][ks], b, acc[mt], 0, 0, 0);
+      }
+      if (px[u] < npx) {
+        float* drow = D + (size_t)px[u] * stride;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = mt * 16 + g * 4 + r;
+            if (m < mrows) drow[m] = acc[mt][r];
+          }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- overlap-add: out[oy][ox][co] = sum over the (<= 2 x 2) taps with ky = oy+1 (mod 2), kx = ox+1 (mod 2)
+  const int oy_lo = 2 * r0, oy_hi = min(2 * (r0 + p.R), p.Ho);
+  const int nout = (oy_hi - oy_lo) * p.Wo;
+  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (p.bias != nullptr && c < p.Cout) bias[c] = p.bias[c];
+  for (int idx = tid; idx < nout; idx += 256) {
+    uint32_t qy, ox;
+    fdivmod((uint32_t)idx, p.fWo, qy, ox);
+    const int oy = oy_lo + (int)qy;
+    const int ky0 = (oy + 1) & 1, kx0 = ((int)ox + 1) & 1;
+    const int iyA = (oy + 1 - ky0) >> 1, ixA = ((int)ox + 1 - kx0) >> 1;
+    float s[4] = {bias[0], bias[1], bias[2], bias[3]};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int iy = iyA - dy, ky = ky0 + 2 * dy;
+      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int ix = ixA - dx, kx = kx0 + 2 * dx;
+        if ((unsigned)ix >= (unsigned)p.Wi) continue;
+        const float* d = D + (size_t)((iy - row_lo) * p.Wi + ix) * stride + (ky * 4 + kx) * p.Cout;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < p.Cout) s[c] += d[c];
+      }
+    }
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < p.Cout) v[c] = act_apply(s[c], p.act, p.slope);
+    store8(p.y + (((size_t)plane * p.Ho + oy) * p.Wo + ox) * p.Cop, v);
+  }
+}
+
+template <int MT, int KS>
+int launch_thin(const ThinP& p, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(convt_thin_kernel<MT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((convt_thin_kernel<MT, KS>), dim3((unsigned)(p.planes * p.nstrips)), dim3(256), lds, st, p);
+  VFD_CHECK_LAUNCH("convt_thin");
+  return 1;
+}
+
+bool small_enabled() {
+  static const bool off = getenv("VFD_NO_SMALL") != nullptr;
+  return !off;
+}
+
+}  // namespace
+
+// Returns 1 when the layer was handled (or, with `query`, would be), 0 when it is not one of the two shapes, < 0 on error.
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, bool want_stats,
+                       bool query, hipStream_t st) {
+  if (!small_enabled() || d->dtype != VFD_BF16 || want_stats) return 0;
+  const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
+  if (!d->transposed) {
+    if (Cip != 8 || d->kh != 4 || d->kw != 4 || d->Cout > 16 * CIN8_NI || d->Cout < 17 || d->kd > 4) return 0;
+    const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
+    if (M >= 0x7fffffffLL / CIN8_TILE * CIN8_TILE || M <= 0) return 0;
+    if (query) return 1;
+    Cin8P p;
+    p.x = reinterpret_cast<const bf16_t*>(x); p.w = reinterpret_cast<const bf16_t*>(packed);
+    p.y = reinterpret_cast<bf16_t*>(y); p.bias = bias;
+    p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
+    p.Cout = d->Cout; p.Cop = Cop;
+    p.kd = d->kd; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
+    p.act = d->act; p.slope = d->slope;
+    p.fWo = make_fastdiv((uint32_t)d->Wo); p.fHo = make_fastdiv((uint32_t)d->Ho); p.fDo = make_fastdiv((uint32_t)d->Do);
+    p.M = M;
+    p.ntiles = (int)((M + CIN8_TILE - 1) / CIN8_TILE);
+    const size_t lds = (size_t)d->kd * 4 * CIN8_NI * 1024;
+    const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
+    hipLaunchKernelGGL(conv_cin8_kernel, dim3((unsigned)blocks), dim3(64 * CIN8_WAVES), lds, st, p);
+    VFD_CHECK_LAUNCH("conv_cin8");
+    return 1;
+  }
+  // ConvTranspose k4 s2 p1 (no output padding) on 2-D planes, thin output
+  if (d->kd != 1 || d->sd != 1 || d->pd != 0 || d->Do != d->Di) return 0;
+  if (d->kh != 4 || d->kw != 4 || d->sh != 2 || d->sw != 2 || d->ph != 1 || d->pw != 1) return 0;
+  if (d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi || d->Cout > 4 || d->Cout == 2) return 0;
+  if (Cip != 32 && Cip != 64 && Cip != 128) return 0;
+  if ((long long)d->N * d->Di * d->Ho * d->Wo * Cop >= (1ll << 40)) return 0;
+  const int stride = 16 * d->Cout + 1;
+  static const int forced_r = getenv("VFD_CONVT_THIN_R") ? atoi(getenv("VFD_CONVT_THIN_R")) : 0;
+  const size_t budget = 80 * 1000;         // two workgroups per CU
+  int R = 0;
+  long long best = -1;
+  for (int r = 1; r <= d->Hi && r <= 16; ++r) {
+    if ((size_t)(r + 2) * d->Wi * stride * 4 > budget) break;
+    const long long cost = (long long)((d->Hi + r - 1) / r) * (r + 2);
+    if (best < 0 || cost < best) { best = cost; R = r; }
+  }
+  if (forced_r > 0 && (size_t)(forced_r + 2) * d->Wi * stride * 4 <= 150 * 1000) R = forced_r < d->Hi ? forced_r : d->Hi;
+  if (R == 0) return 0;
+  const long long planes = (long long)d->N * d->Di;
+  const int nstrips = (d->Hi + R - 1) / R;
+  if (planes * nstrips >= 0x7fffffffLL) return 0;
+  if (query) return 1;
+  ThinP p;
+  p.x = reinterpret_cast<const bf16_t*>(x); p.w = reinterpret_cast<const bf16_t*>(packed);
+  p.y = reinterpret_cast<bf16_t*>(y); p.bias = bias;
+  p.planes = (int)planes; p.Hi = d->Hi; p.Wi = d->Wi; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.Cip = Cip; p.Cout = d->Cout; p.Cop = Cop;
+  p.R = R; p.nstrips = nstrips;
+  p.act = d->act; p.slope = d->slope;
+  p.fWo = make_fastdiv((uint32_t)d->Wo);
+  const size_t lds = (size_t)(R + 2) * d->Wi * stride * 4;
+  const int mt = d->Cout, ks = Cip / 32;
+#define THIN(MT_, KS_) if (mt == MT_ && ks == KS_) return launch_thin<MT_, KS_>(p, lds, st);
+  THIN(1, 1) THIN(1, 2) THIN(1, 4) THIN(3, 1) THIN(3, 2) THIN(3, 4) THIN(4, 1) THIN(4, 2) THIN(4, 4)
+#undef THIN
+  return 0;
+}
