@@ -106,6 +106,11 @@ int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, 
  * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
 int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes);
 
+/* Name of the kernel vfd_conv_forward() dispatches this layer to ("conv_igemm<bf16,256c_x_128p>", "conv_cin8<bf16>",
+ * "convt_thin<bf16>", ...), NUL-terminated into buf[n]: what the profiler rows of bench.py and profiles/ are keyed
+ * on, so that they follow the dispatch rules instead of restating them. */
+int vfd_conv_kernel_name(const vfd_conv_desc* d, int want_stats, char* buf, size_t n);
+
 /* Filter gradient.  Computes, for the conv described by `d` (same desc as forward),
  *     dWp[r][t][c] = sum_{n,q} S[n,q][r] * G[n, q*s-p+t][c]
  * with (S,G) = (dy, x) for transposed = 0 and (x, dy) for transposed = 1, i.e. in the packed layout of

@@ -122,6 +122,27 @@ __device__ __forceinline__ float act_apply(float x, int act, float slope) {
     default: return x;
   }
 }
+// bf16-output kernels: v_exp_f32 / v_rcp_f32 forms (relative error ~1e-6, far inside half a bf16 ulp = 2^-9)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  x = fminf(fmaxf(x, -15.f), 15.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f);
+}
+// the same over a register array with ONE (wave-uniform) dispatch: inside unrolled epilogue loops the per-value switch
+// above is replicated per element, branches included
+template <bool FAST, int N>
+__device__ __forceinline__ void act_apply_n(float (&v)[N], int act, float slope) {
+  if (act == VFD_ACT_LRELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * slope;
+  } else if (act == VFD_ACT_SIGMOID) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = FAST ? fast_sigmoid(v[i]) : 1.f / (1.f + __expf(-v[i]));
+  } else if (act == VFD_ACT_TANH) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = FAST ? fast_tanh(v[i]) : tanhf(v[i]);
+  }
+}
 // derivative expressed from the OUTPUT y = act(x)
 __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
   switch (act) {

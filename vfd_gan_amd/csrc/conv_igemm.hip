@@ -18,8 +18,6 @@
 //     transposed : in = q + c0 - t,  k = k0 + t*s, k0 = (r+p)%s, c0 = (r+p-k0)/s,  out = q*s + r
 #include "common.hpp"
 #include <stdlib.h>
-#include <stdio.h>
-#include <vector>
 
 namespace {
 
@@ -39,7 +37,6 @@ struct ConvP {
   int ksplit;   // >1: K range split over blockIdx.z, raw f32 partial tiles go to ws[ksplit][M][Cop]
   float* ws;
   int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
-  unsigned long long* stamps;   // tuning: per-workgroup s_memtime stamps [blocks][8] (env VFD_IGEMM_STAMPS), else null
 };
 
 struct DimClass {  // per-dimension description of the taps of one output class
@@ -176,10 +173,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + 1024];
-#define VFD_STAMP(i)                                                                                                   \
-  if (p.stamps != nullptr && threadIdx.x == 0)                                                                         \
-    p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime();
-  VFD_STAMP(0)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -273,7 +266,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     }
   };
   enter_tap();
-  VFD_STAMP(1)
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   auto issue_stage = [&](int stage) {
     char* wt = smem + stage * STAGE_BYTES;
@@ -332,7 +324,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       // every wave's step-s DMAs landed AND every wave finished reading the stage the next issue overwrites
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (s == 0) { VFD_STAMP(2) }
       int nstage = stage + STAGES - 1;
       if (nstage >= STAGES) nstage -= STAGES;
       issue_stage(nstage);          // step s + STAGES - 1 (zero page beyond the end: keeps the vmcnt accounting uniform)
@@ -344,7 +335,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     }
     __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0): drain the trailing zero-page DMAs before LDS is released
   }
-  VFD_STAMP(3)
 
   const int cq = (lane >> 4) * 4;
   if (p.ksplit > 1) {
@@ -441,11 +431,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);
     }
   }
-  VFD_STAMP(4)
-  if (p.stamps != nullptr && threadIdx.x == 0)
-    p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) /* HW_ID */
-        | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32) /* XCC_ID */;
-#undef VFD_STAMP
 }
 
 // y[m][c] = act(sum_ks ws[ks][m][c] + bias[c]) for the split-K path (regular convolutions only: out pixel == m)
@@ -485,36 +470,6 @@ int pick_ksplit(const ConvP& p, long long M, int bk) {
   return ks < 2 ? 1 : (int)ks;
 }
 
-// Tuning aid (env VFD_IGEMM_STAMPS): phase durations of the workgroups of one launch, in shader cycles.
-static void report_stamps(unsigned long long* dev, size_t nblocks, int tile_c, int tile_p, hipStream_t st) {
-  (void)hipStreamSynchronize(st);
-  std::vector<unsigned long long> h(nblocks * 8);
-  (void)hipMemcpy(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
-  double ph[4] = {0, 0, 0, 0}, life = 0;
-  unsigned long long tmin = ~0ull, tmax = 0;
-  size_t n = 0;
-  std::vector<int> percu(8 * 64, 0);
-  for (size_t b = 0; b < nblocks; ++b) {
-    const unsigned long long* t = &h[b * 8];
-    if (t[0] == 0 || t[4] == 0) continue;
-    ++n;
-    for (int i = 0; i < 4; ++i) ph[i] += (double)(t[i + 1] > t[i] ? t[i + 1] - t[i] : 0);
-    life += (double)(t[4] - t[0]);
-    if (t[0] < tmin) tmin = t[0];
-    if (t[4] > tmax) tmax = t[4];
-    const unsigned hw = (unsigned)t[5], xcc = (unsigned)(t[5] >> 32) & 15;
-    const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
-    percu[(xcc & 7) * 64 + ((se * 2 + sh) * 16 + cu) % 64]++;
-  }
-  if (n == 0) { fprintf(stderr, "[stamps] no complete workgroups\n"); return; }
-  int cus = 0, mx = 0;
-  for (int v : percu) { if (v) ++cus; if (v > mx) mx = v; }
-  fprintf(stderr, "[stamps] tile %dc x %dp: %zu workgroups on %d CUs (max %d per CU); cycles/workgroup: setup %.0f, first data %.0f, "
-          "main loop %.0f, epilogue %.0f, lifetime %.0f; launch span %.0f cycles\n", tile_c, tile_p, n, cus, mx, ph[0] / n, ph[1] / n,
-          ph[2] / n, ph[3] / n, life / n, (double)(tmax - tmin));
-}
-
 template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB>
 int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   constexpr int TILE_C = WAVES_C * NI * 16;
@@ -529,15 +484,8 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
   dim3 grid((unsigned)mb, (unsigned)((p.Cout + TILE_C - 1) / TILE_C), (unsigned)(ncls * q.ksplit));
   if (grid.y > 65535u || grid.z > 65535u) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
-  static const bool want_stamps = getenv("VFD_IGEMM_STAMPS") != nullptr;
-  const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
-  if (want_stamps) {
-    if (hipMalloc(&q.stamps, nblocks * 8 * sizeof(unsigned long long)) != hipSuccess) q.stamps = nullptr;
-    else (void)hipMemset(q.stamps, 0, nblocks * 8 * sizeof(unsigned long long));
-  }
   hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
-  if (q.stamps != nullptr) report_stamps(q.stamps, nblocks, TILE_C, TILE_P, st);
   if (q.ksplit > 1) {
     const long long total = maxM * (p.Cop >> 3);
     long long nb = (total + 255) / 256;
@@ -630,7 +578,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   p.transposed = d->transposed;
   p.Kw = d->kd * d->kh * d->kw * p.Cip;
   p.act = d->act; p.slope = d->slope;
-  p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws); p.stamps = nullptr;
+  p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
   {
     static const int v = getenv("VFD_IGEMM_VARIANT") ? atoi(getenv("VFD_IGEMM_VARIANT")) : 0;
     p.variant = v;
@@ -646,6 +594,27 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   }
   hipStream_t st = as_stream(stream);
   return d->dtype == VFD_BF16 ? launch<bf16_t>(p, maxM, ncls, st, ws_bytes, ws_query) : launch<float>(p, maxM, ncls, st, ws_bytes, ws_query);
+}
+
+extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, char* buf, size_t n) {
+  VFD_REQUIRE(d_in != nullptr && buf != nullptr && n > 0, "conv_kernel_name: bad arguments");
+  vfd_conv_desc dn = *d_in;
+  if (dn.transposed) {
+    if (dn.Di == 1) dn.sd = dn.kd;
+    if (dn.Hi == 1) dn.sh = dn.kh;
+    if (dn.Wi == 1) dn.sw = dn.kw;
+  }
+  int rc = vfd_conv_check_desc(&dn);
+  if (rc != VFD_OK) return rc;
+  const char* t = dn.dtype == VFD_BF16 ? "bf16" : "f32";
+  if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0, true, nullptr) > 0) {
+    snprintf(buf, n, "%s<%s>", dn.transposed ? "convt_thin" : "conv_cin8", t);
+    return VFD_OK;
+  }
+  const int c = dn.Cout;   // launch<T>() below
+  const char* tile = c > 128 ? "256c_x_128p" : c > 64 ? "128c_x_256p" : c > 32 ? "64c_x_256p" : c > 16 ? "32c_x_256p" : "16c_x_256p";
+  snprintf(buf, n, "conv_igemm<%s,%s>", t, tile);
+  return VFD_OK;
 }
 
 extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes) {

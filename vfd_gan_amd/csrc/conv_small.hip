@@ -57,27 +57,23 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
     if (co < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (nks * 4) + tap) * 8);
     *reinterpret_cast<uint4*>(smem + (size_t)f * 16) = v;
   }
+  // bias (zero beyond Cout) behind the filter fragments and the per-wave transpose tiles
+  float* bias_s = reinterpret_cast<float*>(smem + (size_t)nks * CIN8_NI * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128);
+  if (tid < 16 * CIN8_NI) bias_s[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
   __syncthreads();
 
   const int cq = g * 4;
-  float b4[CIN8_NI][4];
-#pragma unroll
-  for (int i = 0; i < CIN8_NI; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int c = i * 16 + cq + r;
-      b4[i][r] = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
-    }
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    long long base[CIN8_NJ];      // element offset of (n, id0, ih0, iw) — may point outside the block, only used when valid
-    int id0[CIN8_NJ], ih0[CIN8_NJ];
-    bool colok[CIN8_NJ];
-    long long mpix[CIN8_NJ];
+  // ---- loads: the 4 filter rows x NJ fragments of one depth tap are issued back to back.  Every address is in bounds
+  // (masked lanes read the start of the block and are zeroed on use: no branch around a load, no early wait).  Four
+  // waves per SIMD hide the latency; an explicit next-tile prefetch at three measured the same (83 vs 85 us, enc.init).
+  long long base[CIN8_NJ];
+  int id0[CIN8_NJ], ih0[CIN8_NJ];
+  bool colok[CIN8_NJ];
+  auto coords = [&](int tile) {
 #pragma unroll
     for (int j = 0; j < CIN8_NJ; ++j) {
       const long long m = (long long)tile * CIN8_TILE + wave * (CIN8_NJ * 16) + j * 16 + (lane & 15);
-      mpix[j] = m < p.M ? m : -1;
       uint32_t q = (uint32_t)(m < p.M ? m : 0), ow, oh, od;
       fdivmod(q, p.fWo, q, ow);
       fdivmod(q, p.fHo, q, oh);
@@ -89,6 +85,23 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
       colok[j] = m < p.M && (unsigned)iw < (unsigned)p.Wi;
       base[j] = ((((long long)n * p.Di + id0[j]) * p.Hi + ih0[j]) * p.Wi + iw) * 8;
     }
+  };
+  uint4 braw[4][CIN8_NJ];
+  unsigned bok = 0;
+  auto issue = [&](int kz) {
+    bok = 0;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) {
+        const bool ok = colok[j] && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
+        const long long off = ok ? base[j] + ((long long)kz * p.Hi + ky) * p.Wi * 8 : 0;
+        braw[ky][j] = *reinterpret_cast<const uint4*>(p.x + off);
+        bok |= ok ? 1u << (ky * CIN8_NJ + j) : 0u;
+      }
+  };
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     f32x4 acc[CIN8_NI][CIN8_NJ];
 #pragma unroll
     for (int i = 0; i < CIN8_NI; ++i)
@@ -96,56 +109,76 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
       for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int kz = 0; kz < p.kd; ++kz) {
-      // the 4 filter rows of this depth tap: 4 x NJ fragment loads in flight, every address in bounds (masked ones
-      // read the start of the block and are zeroed below: no branch, no early wait)
-      uint4 braw[4][CIN8_NJ];
-      bool bok[4][CIN8_NJ];
+      if (kz == 0) coords(tile);
+      issue(kz);
+      bf16x8 b[4][CIN8_NJ];
 #pragma unroll
       for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
         for (int j = 0; j < CIN8_NJ; ++j) {
-          const bool ok = colok[j] && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
-          const long long off = ok ? base[j] + ((long long)kz * p.Hi + ky) * p.Wi * 8 : 0;
-          braw[ky][j] = *reinterpret_cast<const uint4*>(p.x + off);
-          bok[ky][j] = ok;
+          uint4 v = braw[ky][j];
+          if (!((bok >> (ky * CIN8_NJ + j)) & 1u)) v = make_uint4(0, 0, 0, 0);
+          b[ky][j] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
       for (int ky = 0; ky < 4; ++ky) {
         const int ks = kz * 4 + ky;
-        bf16x8 a[CIN8_NI], b[CIN8_NJ];
+        bf16x8 a[CIN8_NI];
 #pragma unroll
         for (int i = 0; i < CIN8_NI; ++i)
           a[i] = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(ks * CIN8_NI + i) * 64 + lane) * 16);
 #pragma unroll
-        for (int j = 0; j < CIN8_NJ; ++j) {
-          uint4 v = braw[ky][j];
-          if (!bok[ky][j]) v = make_uint4(0, 0, 0, 0);
-          b[j] = __builtin_bit_cast(bf16x8, v);
-        }
-#pragma unroll
         for (int i = 0; i < CIN8_NI; ++i)
 #pragma unroll
-          for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[ky][j], acc[i][j], 0, 0, 0);
       }
     }
 
-    // ---- epilogue: bias, activation, channels-last store (out pixel == m for a regular convolution)
+    // ---- epilogue: bias + activation, then a transpose through this wave's 4 KiB of LDS so that every lane stores 16
+    // bytes and a wave-instruction covers 8 whole pixels (1 KiB contiguous: out pixel == m for a regular convolution)
+    // instead of 16 pixels x 32 bytes.  8-byte unit u of pixel row n sits at slot u ^ n: conflict-free for the
+    // ds_write_b64 (16 pixels of one unit) and for the ds_read_b128 (8 chunks of one pixel).
+    char* ot = smem + (size_t)nks * CIN8_NI * 1024 + wave * (CIN8_NJ * 16 * 128);
+    float v[CIN8_NI * CIN8_NJ * 4];
+#pragma unroll
+    for (int i = 0; i < CIN8_NI; ++i) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias_s + i * 16 + cq);
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) {
+        float* o = v + (i * CIN8_NJ + j) * 4;
+        o[0] = acc[i][j][0] + b4.x; o[1] = acc[i][j][1] + b4.y; o[2] = acc[i][j][2] + b4.z; o[3] = acc[i][j][3] + b4.w;
+      }
+    }
+    act_apply_n<true>(v, p.act, p.slope);
+    if (p.act == VFD_ACT_SIGMOID) {   // pad channels stay zero (filter rows and bias beyond Cout are zero; sigmoid(0) is not)
+#pragma unroll
+      for (int i = 0; i < CIN8_NI; ++i)
+#pragma unroll
+        for (int j = 0; j < CIN8_NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (i * 16 + cq + r >= p.Cout) v[(i * CIN8_NJ + j) * 4 + r] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < CIN8_NJ; ++j) {
-      if (mpix[j] < 0) continue;
-      bf16_t* dst = p.y + mpix[j] * p.Cop;
+      const int n = lane & 15;
 #pragma unroll
       for (int i = 0; i < CIN8_NI; ++i) {
-        const int c = i * 16 + cq;
-        if (c >= p.Cop) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (c + r < p.Cout) ? act_apply(acc[i][j][r] + b4[i][r], p.act, p.slope) : 0.f;
+        const float* o4 = v + (i * CIN8_NJ + j) * 4;
         uint2 o;
-        o.x = pack2bf(v[0], v[1]);
-        o.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(dst + c) = o;
+        o.x = pack2bf(o4[0], o4[1]);
+        o.y = pack2bf(o4[2], o4[3]);
+        *reinterpret_cast<uint2*>(ot + (j * 16 + n) * 128 + (((i * 4 + g) ^ n) << 3)) = o;
       }
+    }
+    const long long mw = (long long)tile * CIN8_TILE + wave * (CIN8_NJ * 16);
+#pragma unroll
+    for (int it = 0; it < CIN8_NJ * 2; ++it) {
+      const int px = it * 8 + (lane >> 3), c = lane & 7, n = px & 15;
+      uint4 v = *reinterpret_cast<const uint4*>(ot + px * 128 + ((c ^ (n >> 1)) << 4));
+      if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+      if (mw + px < p.M && c * 8 < p.Cop)
+        *reinterpret_cast<uint4*>(p.y + (mw + px) * p.Cop + c * 8) = v;
     }
   }
 }
@@ -162,13 +195,19 @@ struct ThinP {
   int R, nstrips;       // input rows per strip (plus one halo row on either side)
   int act;
   float slope;
-  FastDiv fWo;
+  FastDiv fWo, fWi;
 };
 
+// MT = Cout (row m = tap * Cout + co, 16 * Cout rows = MT MFMA row tiles), KS = CPAD(Cin) / 32
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void convt_thin_kernel(const ThinP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // D[(R+2)*Wi pixels][16*Cout + 1] float
+  // D[R+2 rows][Wi+2 columns][16*Cout + 1] float: input rows r0-1 .. r0+R, columns -1 .. Wi; whatever lies outside the
+  // image is a zero guard, so the overlap-add below needs no bounds test
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   float* D = reinterpret_cast<float*>(smem);
+  constexpr int COUT = MT;
+  constexpr int MROWS = 16 * COUT;
+  constexpr int STRIDE = MROWS + 1;      // odd: the pixel-strided accesses spread over all banks
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -180,37 +219,46 @@ __global__ __launch_bounds__(256) void convt_thin_kernel(const ThinP p) {
   const int row_hi = min(r0 + p.R + 1, p.Hi);
   const int npx = (row_hi - row_lo) * p.Wi;
   const int ntile = (npx + 15) >> 4;
-  const int mrows = 16 * p.Cout;
-  const int stride = mrows + 1;      // odd: the pixel-strided accesses below spread over all banks
+  const int W2 = p.Wi + 2;
 
-  // filter fragments, resident in registers: row m = tap * Cout + co
+  // filter fragments, resident in registers
   bf16x8 a[MT][KS];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mt * 16 + (lane & 15);
-    const int tap = m / p.Cout, co = m - tap * p.Cout;
+    const int tap = m / COUT, co = m - tap * COUT;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < mrows) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * 16 + tap) * p.Cip + ks * 32 + g * 8);
-      a[mt][ks] = __builtin_bit_cast(bf16x8, v);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+      a[mt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p.w + ((size_t)co * 16 + tap) * p.Cip + ks * 32 + g * 8));
   }
 
+  // zero guards: the two guard columns of every row, and the rows above / below the image
+  for (int i = tid; i < (p.R + 2) * 2 * MROWS; i += 256) {
+    const int m = i % MROWS, e = i / MROWS;
+    D[((e >> 1) * W2 + ((e & 1) ? p.Wi + 1 : 0)) * STRIDE + m] = 0.f;
+  }
+  if (r0 == 0)
+    for (int i = tid; i < p.Wi * MROWS; i += 256) D[(1 + i / MROWS) * STRIDE + i % MROWS] = 0.f;
+  for (int rr = row_hi - (r0 - 1); rr < p.R + 2; ++rr)
+    for (int i = tid; i < p.Wi * MROWS; i += 256) D[(rr * W2 + 1 + i / MROWS) * STRIDE + i % MROWS] = 0.f;
+
   const bf16_t* xs = p.x + ((size_t)plane * p.Hi + row_lo) * p.Wi * p.Cip;
-  // ---- D = W^T x over the strip's pixels, 16 pixels per MFMA column tile, 2 tiles per wave and pass
-  for (int t0 = wave * 2; t0 < ntile; t0 += 8) {
-    uint4 braw[2][KS];
-    int px[2];
+  const int slot0 = (row_lo - (r0 - 1)) * W2 + 1;
+  // ---- D = W^T x over the strip's pixels, 16 pixels per MFMA column tile; a wave issues the loads of up to TPW of its
+  // tiles back to back (one memory latency per pass, not one per tile)
+  constexpr int TPW = KS <= 2 ? 6 : 3;
+  for (int t0 = 0; t0 < ntile; t0 += 4 * TPW) {
+    uint4 braw[TPW][KS];
+    int px[TPW];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      px[u] = (t0 + u) * 16 + (lane & 15);
+    for (int u = 0; u < TPW; ++u) {
+      px[u] = (t0 + wave + 4 * u) * 16 + (lane & 15);
       const int pc = px[u] < npx ? px[u] : 0;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) braw[u][ks] = *reinterpret_cast<const uint4*>(xs + (size_t)pc * p.Cip + ks * 32 + g * 8);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TPW; ++u) {
       f32x4 acc[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -221,52 +269,54 @@ __global__ __launch_bounds__(256) void convt_thin_kernel(const ThinP p) {
         for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][ks], b, acc[mt], 0, 0, 0);
       }
       if (px[u] < npx) {
-        float* drow = D + (size_t)px[u] * stride;
+        const uint32_t rl = fdiv((uint32_t)px[u], p.fWi);
+        float* drow = D + (slot0 + (int)rl * 2 + px[u]) * STRIDE + g * 4;      // slot = slot0 + rl * W2 + (px - rl * Wi)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = mt * 16 + g * 4 + r;
-            if (m < mrows) drow[m] = acc[mt][r];
-          }
+          for (int r = 0; r < 4; ++r) drow[mt * 16 + r] = acc[mt][r];
       }
     }
   }
   __syncthreads();
 
-  // ---- overlap-add: out[oy][ox][co] = sum over the (<= 2 x 2) taps with ky = oy+1 (mod 2), kx = ox+1 (mod 2)
+  // ---- overlap-add: out[oy][ox][co] = sum over the 2 x 2 taps with ky = oy+1 (mod 2), kx = ox+1 (mod 2), in a fixed
+  // order; 4 output pixels per thread and pass so that their LDS reads are all in flight together
   const int oy_lo = 2 * r0, oy_hi = min(2 * (r0 + p.R), p.Ho);
   const int nout = (oy_hi - oy_lo) * p.Wo;
-  float bias[4] = {0.f, 0.f, 0.f, 0.f};
+  float bias[COUT];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (p.bias != nullptr && c < p.Cout) bias[c] = p.bias[c];
-  for (int idx = tid; idx < nout; idx += 256) {
-    uint32_t qy, ox;
-    fdivmod((uint32_t)idx, p.fWo, qy, ox);
-    const int oy = oy_lo + (int)qy;
-    const int ky0 = (oy + 1) & 1, kx0 = ((int)ox + 1) & 1;
-    const int iyA = (oy + 1 - ky0) >> 1, ixA = ((int)ox + 1 - kx0) >> 1;
-    float s[4] = {bias[0], bias[1], bias[2], bias[3]};
+  for (int c = 0; c < COUT; ++c) bias[c] = p.bias != nullptr ? p.bias[c] : 0.f;
+  bf16_t* yrow = p.y + ((size_t)plane * p.Ho + oy_lo) * p.Wo * p.Cop;
+  for (int i0 = 0; i0 < nout; i0 += 1024) {
+    float s[4][COUT];
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int iy = iyA - dy, ky = ky0 + 2 * dy;
-      if ((unsigned)iy >= (unsigned)p.Hi) continue;
+    for (int k = 0; k < 4; ++k) {
+      const int idx = min(i0 + k * 256 + tid, nout - 1);
+      uint32_t oyl, ox;
+      fdivmod((uint32_t)idx, p.fWo, oyl, ox);
+      const int ky0 = ((int)oyl + 1) & 1, kx0 = ((int)ox + 1) & 1;
+      const int rrA = (((int)oyl + 1 - ky0) >> 1) + 1, ccA = (((int)ox + 1 - kx0) >> 1) + 1;
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int ix = ixA - dx, kx = kx0 + 2 * dx;
-        if ((unsigned)ix >= (unsigned)p.Wi) continue;
-        const float* d = D + (size_t)((iy - row_lo) * p.Wi + ix) * stride + (ky * 4 + kx) * p.Cout;
+      for (int c = 0; c < COUT; ++c) s[k][c] = bias[c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (c < p.Cout) s[c] += d[c];
-      }
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const float* d = D + ((rrA - dy) * W2 + ccA - dx) * STRIDE + ((ky0 + 2 * dy) * 4 + kx0 + 2 * dx) * COUT;
+#pragma unroll
+          for (int c = 0; c < COUT; ++c) s[k][c] += d[c];
+        }
     }
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (c < p.Cout) v[c] = act_apply(s[c], p.act, p.slope);
-    store8(p.y + (((size_t)plane * p.Ho + oy) * p.Wo + ox) * p.Cop, v);
+    for (int k = 0; k < 4; ++k) {
+      act_apply_n<true>(s[k], p.act, p.slope);
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) v[c] = s[k][c];
+      const int idx = i0 + k * 256 + tid;
+      if (idx < nout) store8(yrow + (size_t)idx * p.Cop, v);
+    }
   }
 }
 
@@ -310,7 +360,7 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
     p.fWo = make_fastdiv((uint32_t)d->Wo); p.fHo = make_fastdiv((uint32_t)d->Ho); p.fDo = make_fastdiv((uint32_t)d->Do);
     p.M = M;
     p.ntiles = (int)((M + CIN8_TILE - 1) / CIN8_TILE);
-    const size_t lds = (size_t)d->kd * 4 * CIN8_NI * 1024;
+    const size_t lds = (size_t)d->kd * 4 * CIN8_NI * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128 + 16 * CIN8_NI * sizeof(float);
     const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
     hipLaunchKernelGGL(conv_cin8_kernel, dim3((unsigned)blocks), dim3(64 * CIN8_WAVES), lds, st, p);
     VFD_CHECK_LAUNCH("conv_cin8");
@@ -328,11 +378,11 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
   int R = 0;
   long long best = -1;
   for (int r = 1; r <= d->Hi && r <= 16; ++r) {
-    if ((size_t)(r + 2) * d->Wi * stride * 4 > budget) break;
+    if ((size_t)(r + 2) * (d->Wi + 2) * stride * 4 > budget) break;
     const long long cost = (long long)((d->Hi + r - 1) / r) * (r + 2);
     if (best < 0 || cost < best) { best = cost; R = r; }
   }
-  if (forced_r > 0 && (size_t)(forced_r + 2) * d->Wi * stride * 4 <= 150 * 1000) R = forced_r < d->Hi ? forced_r : d->Hi;
+  if (forced_r > 0 && (size_t)(forced_r + 2) * (d->Wi + 2) * stride * 4 <= 150 * 1000) R = forced_r < d->Hi ? forced_r : d->Hi;
   if (R == 0) return 0;
   const long long planes = (long long)d->N * d->Di;
   const int nstrips = (d->Hi + R - 1) / R;
@@ -346,7 +396,8 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
   p.R = R; p.nstrips = nstrips;
   p.act = d->act; p.slope = d->slope;
   p.fWo = make_fastdiv((uint32_t)d->Wo);
-  const size_t lds = (size_t)(R + 2) * d->Wi * stride * 4;
+  p.fWi = make_fastdiv((uint32_t)d->Wi);
+  const size_t lds = (size_t)(R + 2) * (d->Wi + 2) * stride * 4;
   const int mt = d->Cout, ks = Cip / 32;
 #define THIN(MT_, KS_) if (mt == MT_ && ks == KS_) return launch_thin<MT_, KS_>(p, lds, st);
   THIN(1, 1) THIN(1, 2) THIN(1, 4) THIN(3, 1) THIN(3, 2) THIN(3, 4) THIN(4, 1) THIN(4, 2) THIN(4, 4)

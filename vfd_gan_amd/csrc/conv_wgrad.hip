@@ -279,7 +279,7 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   long long nsplit = 768 / tiles;   // one round of 3 resident workgroups per CU
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
   if (nsplit > maxsplit) nsplit = maxsplit;
-  if (nsplit > 256) nsplit = 256;
+  if (nsplit > 1024) nsplit = 1024;
   if (nsplit < 1) nsplit = 1;
   const size_t slab = (size_t)p.Cs * p.ncols * sizeof(float);
   while (nsplit > 1 && slab * (size_t)nsplit > ((size_t)512 << 20)) nsplit /= 2;

@@ -297,13 +297,11 @@ def set_kernel_timer(t):
     _TIMER[0] = t
 
 
-def _igemm_name(desc):
-    """Name of the conv_igemm instantiation vfd_conv_forward dispatches to (conv_igemm.hip: launch<T>)."""
-    t = "bf16" if desc.dtype == _lib.BF16 else "f32"
-    c = desc.Cout
-    tile = ("256c_x_128p" if c > 128 else "128c_x_256p") if c > 64 else (
-        "64c_x_256p" if c > 32 else ("32c_x_256p" if c > 16 else "16c_x_256p"))
-    return "conv_igemm<%s,%s>" % (t, tile)
+def _conv_kernel_name(desc, stats=None):
+    """Name of the kernel vfd_conv_forward dispatches this layer to (asked of the library, not restated here)."""
+    buf = ctypes.create_string_buffer(96)
+    check(load().vfd_conv_kernel_name(ctypes.byref(desc), int(stats is not None), buf, 96), "conv_kernel_name")
+    return buf.value.decode()
 
 
 def _geom_str(desc, stats=None):
@@ -336,7 +334,7 @@ def _conv_launch(desc, x, packed, bias, out, stats=None):
           "conv_forward")
     if timer is not None:
         e1.record()
-        timer.records.append((_igemm_name(desc), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
+        timer.records.append((_conv_kernel_name(desc, stats), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
 
 
 class _Conv(torch.autograd.Function):
