@@ -354,74 +354,122 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   }
 
   // ---- epilogue: bias, statistics, activation, channels-last store --------------------------------------
-  // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time)
+  // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time; the activation is
+  // dispatched ONCE around the loops: a per-value switch is replicated, branches included, in every unrolled copy)
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  long long opix[NJ];     // output pixel offset in elements (pixel * Cop), or -1
+  const bool want_stats = p.stats != nullptr;
+  // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
+  // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
+  // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
+  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64;
+  constexpr int OUT_BYTES = VIA_LDS ? TILE_P * TILE_C * 2 : 0;
+  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
+  static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024, "epilogue LDS exceeds the staging ring");
+  // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
+  // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
+  // same 2*Cout addresses; bn_from_sums folds the replicas).
+  float* red = reinterpret_cast<float*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
+  long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
+  auto out_offset = [&](long long m) -> long long {
+    if (m >= Mcls) return -1;
+    uint32_t q = (uint32_t)m, qw, qh, qd;
+    fdivmod(q, dw.fq, q, qw);
+    fdivmod(q, dh.fq, q, qh);
+    fdivmod(q, dd.fq, q, qd);
+    const int n = (int)q;
+    return ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
+  };
+  long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
+  bool pvalid[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
-    opix[j] = -1;
-    if (m < Mcls) {
-      uint32_t q = (uint32_t)m, qw, qh, qd;
-      fdivmod(q, dw.fq, q, qw);
-      fdivmod(q, dh.fq, q, qh);
-      fdivmod(q, dd.fq, q, qd);
-      const int n = (int)q;
-      opix[j] = ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
+    pvalid[j] = m < Mcls;
+    if constexpr (!VIA_LDS) opix[j] = out_offset(m);
+  }
+  if (VIA_LDS || want_stats) __syncthreads();      // every wave is done reading the last stage
+  if constexpr (VIA_LDS) {
+    for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(m0 + r);
+  }
+  auto body = [&](auto actf) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = n0 + wave_c0 + i * 16 + cq;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
+      }
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[i][j][r] + b4[r];
+          if (want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+          v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
+        }
+        if constexpr (VIA_LDS) {
+          // 8-byte unit u of tile row (pixel) with row & 15 == n sits at slot u ^ n: the 16 rows of one ds_write_b64
+          // group land on 16 different bank pairs, and a pixel's 16-byte chunk c is found whole at c ^ (n >> 1)
+          const int n = lane & 15;
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(smem + (wave_p0 + j * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
+        } else {
+          if (opix[j] >= 0 && c < p.Cop) {
+            T* dst = yg + opix[j] + c;
+            if constexpr (sizeof(T) == 2) {
+              uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+              *reinterpret_cast<uint2*>(dst) = o;
+            } else {
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s1[r], b = s2[r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if ((lane & 15) == 0) {
+            const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
+            red[cl * WAVES_P + (wave / WAVES_C)] = a;
+            red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
+          }
+        }
+      }
+    }
+  };
+  {
+    const float slope = p.slope;
+    constexpr bool FAST = sizeof(T) == 2;     // bf16 output: v_exp/v_rcp forms are exact to far below half an ulp
+    switch (p.act) {
+      case VFD_ACT_LRELU: body([slope](float t) { return t > 0.f ? t : t * slope; }); break;
+      case VFD_ACT_SIGMOID: body([](float t) { return FAST ? fast_sigmoid(t) : 1.f / (1.f + __expf(-t)); }); break;
+      case VFD_ACT_TANH: body([](float t) { return FAST ? fast_tanh(t) : tanhf(t); }); break;
+      default: body([](float t) { return t; }); break;
     }
   }
-  const bool want_stats = p.stats != nullptr;
-  // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS, reusing the staging ring) -> ONE float atomic
-  // per channel and workgroup into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of
-  // workgroups adding into the same 2*Cout addresses; bn_from_sums folds the replicas).
-  float* red = reinterpret_cast<float*>(smem);     // [2][TILE_C][WAVES_P]
-  if (want_stats) __syncthreads();                 // every wave is done reading the last stage
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int c = n0 + wave_c0 + i * 16 + cq;
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const bool mvalid = opix[j] >= 0;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float t = acc[i][j][r] + b4[r];
-        if (want_stats && mvalid) { s1[r] += t; s2[r] += t * t; }
-        v[r] = ((c + r) < p.Cout) ? act_apply(t, p.act, p.slope) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
-      }
-      if (mvalid && c < p.Cop) {
-        T* dst = yg + opix[j] + c;
-        if constexpr (sizeof(T) == 2) {
-          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(dst) = o;
-        } else {
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-    }
-    if (want_stats) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[r], b = s2[r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        if ((lane & 15) == 0) {
-          const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
-          red[cl * WAVES_P + (wave / WAVES_C)] = a;
-          red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
-        }
-      }
+  if (VIA_LDS || want_stats) __syncthreads();
+  if constexpr (VIA_LDS) {
+    constexpr int CPRW = TILE_C / 8;          // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPRW;            // tile rows per wave-instruction
+    const int c = lane % CPRW;
+    const bool cok = n0 + c * 8 < p.Cop;
+#pragma unroll 4
+    for (int it = wave; it < TILE_P / RPW; it += NWAVES) {
+      const int row = it * RPW + lane / CPRW, n = row & 15;
+      uint4 v = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
+      if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+      const long long off = orow[row];
+      if (off >= 0 && cok) *reinterpret_cast<uint4*>(yg + off + n0 + c * 8) = v;
     }
   }
   if (want_stats) {
-    __syncthreads();
     float* rep = p.stats + (size_t)((blockIdx.x + blockIdx.z) % VFD_STATS_REPLICAS) * 2 * p.Cop;
     for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
       const int which = t / TILE_C, cl = t - which * TILE_C;
