@@ -58,11 +58,20 @@ void run(const char* src, size_t span, int row_stride, int blocks, int nthreads,
 int main() {
   const size_t big = (size_t)1 << 30;
   char* src; CK(hipMalloc(&src, big)); CK(hipMemset(src, 1, big));
-  for (size_t span : {(size_t)4 << 20, (size_t)64 << 20}) {
-    for (int stride : {128, 512, 1024, 2048, 4096, 8192, 8192 + 256, 16384}) {
-      run<64, 6, false>(src, span, stride, 512, 512, "dma");
-      run<128, 6, false>(src, span, stride, 512, 512, "dma");
-    }
+  // (1) contiguous run per row, L2-resident vs streaming working set
+  for (size_t span : {(size_t)2 << 20, (size_t)1 << 30}) {
+    run<64, 6, false>(src, span, 512, 512, 512, "dma");
+    run<128, 6, false>(src, span, 512, 512, 512, "dma");
+    run<256, 6, false>(src, span, 512, 512, 512, "dma");
+    run<1024, 6, false>(src, span, 1024, 512, 512, "dma");
+    run<64, 12, false>(src, span, 512, 512, 512, "dma");
+    run<64, 6, true>(src, span, 512, 512, 512, "reg");
+    run<1024, 6, true>(src, span, 1024, 512, 512, "reg");
+  }
+  // (2) row stride (filter rows are Kw*2 bytes apart, e.g. 8 KiB: no channel-conflict effect)
+  for (int stride : {128, 1024, 8192, 8192 + 256}) {
+    run<64, 6, false>(src, (size_t)4 << 20, stride, 512, 512, "dma");
+    run<128, 6, false>(src, (size_t)4 << 20, stride, 512, 512, "dma");
   }
   return 0;
 }

@@ -361,9 +361,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
-  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64;
-  constexpr int OUT_BYTES = VIA_LDS ? TILE_P * TILE_C * 2 : 0;
   constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
+  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64 && TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024;
+  constexpr int OUT_BYTES = VIA_LDS ? TILE_P * TILE_C * 2 : 0;
   static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024, "epilogue LDS exceeds the staging ring");
   // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
