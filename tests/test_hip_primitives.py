@@ -32,6 +32,9 @@ CONV_CASES = [
     ("K6_convT2d_k4s2", (2, 24, 7, 7), 12, 4, 2, 1, 0, True, False),
     ("K6_convT2d_to3", (2, 16, 8, 8), 3, 4, 2, 1, 0, True, False),
     ("K6_conv2d_extra_k3", (2, 16, 8, 8), 16, 3, 1, 1, 0, False, False),
+    # >= 256 channels on the strided side: the 8-wave 256 x 128 filter-gradient tile (partial second tile)
+    ("K6_conv2d_k4s2_cout264", (2, 24, 10, 10), 264, 4, 2, 1, 0, False, True),
+    ("K6_convT2d_k4s2_cin260", (2, 260, 5, 5), 20, 4, 2, 1, 0, True, False),
     # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients
     ("K6_conv2d_first_3to64", (3, 3, 20, 14), 64, 4, 2, 1, 0, False, True),
     ("K6_conv2d_first_3to40", (2, 3, 18, 22), 40, 4, 2, 1, 0, False, False),

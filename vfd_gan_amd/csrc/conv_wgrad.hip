@@ -10,6 +10,7 @@
 // The pixel range is split over blockIdx.z; every split writes its own float32 slab (no atomics, bitwise
 // reproducible); vfd_wgrad_reduce folds the slabs into the torch-layout gradient.
 #include "common.hpp"
+#include <stdlib.h>
 
 int vfd_conv_check_desc(const vfd_conv_desc* d);
 
@@ -47,16 +48,17 @@ template <> struct WgTraits<float> {
 };
 
 // fragment loads: `c0` = first channel of the 16-wide fragment
+template <int ROWB>
 __device__ __forceinline__ bf16x8 frag_tr_bf16(const char* tile, int c0, int lane) {
   // lane = 16g + 4q + pp supplies the address of pixel row (4g + q [+16]), channels c0 + 4pp..+3;
   // it receives channel c0 + (lane & 15) of the 4 rows of its group -> MFMA k = 8g + j  (j<4: first read)
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int row = 4 * g + q;
   const int ch = c0 + 4 * pp;
-  const int off = row * 256 + ((((ch >> 3) ^ WgTraits<bf16_t>::swz(row)) << 4) | ((ch & 4) << 1));
+  const int off = row * ROWB + ((((ch >> 3) ^ WgTraits<bf16_t>::swz(row)) << 4) | ((ch & 4) << 1));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 16 * 256));   // row + 16: same row & 7
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 16 * ROWB));   // row + 16: same row & 7
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
@@ -64,13 +66,14 @@ __device__ __forceinline__ bf16x8 frag_tr_bf16(const char* tile, int c0, int lan
 
 template <typename T> struct WgMma;
 template <> struct WgMma<bf16_t> {
+  template <int SROWB, int GROWB>
   __device__ static __forceinline__ void step(const char* st, const char* gt, int r0, int c0, int lane,
                                               f32x4 (&acc)[4][4]) {
     bf16x8 a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = frag_tr_bf16(st, r0 + i * 16, lane);
+    for (int i = 0; i < 4; ++i) a[i] = frag_tr_bf16<SROWB>(st, r0 + i * 16, lane);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = frag_tr_bf16(gt, c0 + j * 16, lane);
+    for (int j = 0; j < 4; ++j) b[j] = frag_tr_bf16<GROWB>(gt, c0 + j * 16, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -78,9 +81,11 @@ template <> struct WgMma<bf16_t> {
   }
 };
 template <> struct WgMma<float> {
+  template <int ROWB>
   __device__ static __forceinline__ int off(int px, int c) {
-    return px * 512 + ((((c >> 2) ^ WgTraits<float>::swz(px)) << 4) | ((c & 3) << 2));
+    return px * ROWB + ((((c >> 2) ^ WgTraits<float>::swz(px)) << 4) | ((c & 3) << 2));
   }
+  template <int SROWB, int GROWB>
   __device__ static __forceinline__ void step(const char* st, const char* gt, int r0, int c0, int lane,
                                               f32x4 (&acc)[4][4]) {
     const int r = lane & 15, kq = lane >> 4;
@@ -89,9 +94,9 @@ template <> struct WgMma<float> {
       float a[4], b[4];
       const int px = kk * 4 + kq;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float*>(st + off(px, r0 + i * 16 + r));
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const float*>(st + off<SROWB>(px, r0 + i * 16 + r));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float*>(gt + off(px, c0 + j * 16 + r));
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const float*>(gt + off<GROWB>(px, c0 + j * 16 + r));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -104,37 +109,44 @@ __device__ uint4 g_wg_zero_page[4];   // source of every masked 16-byte chunk (s
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-template <typename T, int STAGES>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgP p) {
+// WR x WC waves of 64 x 64 outputs each: tile = 64*WR channels of S x 64*WC flattened columns of G.
+// 2 x 2 (4 waves, 3 workgroups per CU) for narrow layers; 4 x 2 (8 waves, 2 per CU) where S has >= 256 channels and
+// 2 x 4 where it has 65..128: 24 KiB of DMA per 32-pixel step instead of 16 KiB for twice the MFMA work.
+template <typename T, int STAGES, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad_kernel(const WgP p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KP = WgTraits<T>::KP;
-  constexpr int ROWB = WgTraits<T>::ROWB;
-  constexpr int CPR = ROWB / 16;         // 16-byte chunks per tile row (16 bf16 / 32 f32)
-  constexpr int RPI = 64 / CPR;          // pixel rows per 1-KiB DMA wave-instruction (4 / 2)
-  constexpr int NINST = KP / RPI;        // DMA instructions per tile and stage (8)
-  constexpr int NT = NINST / 4;          // per wave and tile (2)
-  constexpr int TILE_BYTES = KP * ROWB;  // 8 KiB
-  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-  static_assert(NINST == 8, "tile shape");
+  constexpr int NW = WR * WC;                 // waves
+  constexpr int TR = 64 * WR, TC = 64 * WC;   // tile rows (S channels), tile columns
+  constexpr int SROWB = TR * (int)sizeof(T), GROWB = TC * (int)sizeof(T);   // bytes per pixel row of the two tiles
+  constexpr int S_CPR = SROWB / 16, G_CPR = GROWB / 16;   // 16-byte chunks per tile row
+  constexpr int S_RPI = 64 / S_CPR, G_RPI = 64 / G_CPR;   // pixel rows per 1-KiB DMA wave-instruction
+  constexpr int S_NT = KP / S_RPI / NW, G_NT = KP / G_RPI / NW;   // DMA instructions per wave, tile and stage
+  constexpr int S_BYTES = KP * SROWB, G_BYTES = KP * GROWB;
+  constexpr int STAGE_BYTES = S_BYTES + G_BYTES;
+  static_assert(S_NT >= 1 && G_NT >= 1 && S_NT * S_RPI * NW == KP && G_NT * G_RPI * NW == KP, "tile shape");
+  // the source-side swizzle of a lane must not depend on the instruction index i (row = RPI * (wave + NW * i) + lrow)
+  static_assert((S_RPI * NW) % 8 == 0 && (G_RPI * NW) % 8 == 0, "swizzle period");
 
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr0 = (wave & 1) * 64, wc0 = (wave >> 1) * 64;
-  const int r0 = blockIdx.y * 128;    // first S channel of this tile
-  const int nb0 = blockIdx.x * 128;   // first flattened column of this tile
+  const int wr0 = (wave % WR) * 64, wc0 = (wave / WR) * 64;
+  const int r0 = blockIdx.y * TR;     // first S channel of this tile
+  const int nb0 = blockIdx.x * TC;    // first flattened column of this tile
   const long long mbeg = (long long)blockIdx.z * p.chunkM;
   long long mend = mbeg + p.chunkM;
   if (mend > p.M) mend = p.M;
   const int nsteps = (mbeg < mend) ? (int)((mend - mbeg + KP - 1) / KP) : 0;
 
   // DMA bookkeeping: lane -> (pixel row within a group, physical slot); logical chunk = slot ^ swz(row)
-  const int lrow = lane / CPR;
-  const int chunk = (lane % CPR) ^ WgTraits<T>::swz(RPI * (wave & 1) + lrow);   // row & 7 depends on wave & 1 and lrow only
-  const int sc = r0 + chunk * VEC;
+  const int s_lrow = lane / S_CPR, g_lrow = lane / G_CPR;
+  const int s_chunk = (lane % S_CPR) ^ WgTraits<T>::swz(S_RPI * wave + s_lrow);
+  const int g_chunk = (lane % G_CPR) ^ WgTraits<T>::swz(G_RPI * wave + g_lrow);
+  const int sc = r0 + s_chunk * VEC;
   const bool sc_ok = sc < p.Csp;
-  const int col = nb0 + chunk * VEC;
+  const int col = nb0 + g_chunk * VEC;
   const bool col_ok = col < p.ncols;
   int gt_d = 0, gt_h = 0, gt_w = 0, gch = 0;
   if (col_ok) {
@@ -150,16 +162,20 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgP p) {
 
   auto issue_stage = [&](int stage, int s) {
     char* st = smem + stage * STAGE_BYTES;
-    char* gt = st + TILE_BYTES;
+    char* gt = st + S_BYTES;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int g = wave + 4 * i;
-      const long long m = mbeg + (long long)s * KP + g * RPI + lrow;
-      const bool mok = m < mend;
-      const char* ssrc = (mok && sc_ok) ? reinterpret_cast<const char*>(Sg + (size_t)m * p.Csp + sc) : zero;
+    for (int i = 0; i < S_NT; ++i) {
+      const int g = wave + NW * i;
+      const long long m = mbeg + (long long)s * KP + g * S_RPI + s_lrow;
+      const char* ssrc = (m < mend && sc_ok) ? reinterpret_cast<const char*>(Sg + (size_t)m * p.Csp + sc) : zero;
       __builtin_amdgcn_global_load_lds((glb_void_t*)ssrc, (lds_void_t*)(st + g * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < G_NT; ++i) {
+      const int g = wave + NW * i;
+      const long long m = mbeg + (long long)s * KP + g * G_RPI + g_lrow;
       const char* gsrc = zero;
-      if (mok && col_ok) {
+      if (m < mend && col_ok) {
         uint32_t q = (uint32_t)m, qw, qh, qd;
         fdivmod(q, p.fQw, q, qw);
         fdivmod(q, p.fQh, q, qh);
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgP p) {
     int stage = 0;
     for (int s = 0; s < nsteps; ++s) {
       {
-        constexpr int N = 2 * NT * (STAGES - 2);
+        constexpr int N = (S_NT + G_NT) * (STAGES - 2);
         __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));   // vmcnt(N)
       }
       __builtin_amdgcn_s_barrier();
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_kernel(const WgP p) {
       if (nstage >= STAGES) nstage -= STAGES;
       issue_stage(nstage, s + STAGES - 1);
       const char* st = smem + stage * STAGE_BYTES;
-      WgMma<T>::step(st, st + TILE_BYTES, wr0, wc0, lane, acc);
+      WgMma<T>::template step<SROWB, GROWB>(st, st + S_BYTES, wr0, wc0, lane, acc);
       if (++stage == STAGES) stage = 0;
     }
     __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0)
@@ -249,6 +265,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct WgGeom {
   WgP p;
   int A, B, T, nsplit;
+  int tr, tc;     // tile: S channels x flattened columns
   size_t bytes;
 };
 
@@ -275,8 +292,13 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   p.fQw = make_fastdiv((uint32_t)p.Qw); p.fQh = make_fastdiv((uint32_t)p.Qh); p.fQd = make_fastdiv((uint32_t)p.Qd);
   VFD_REQUIRE(p.M < 0x7fffffffLL, "wgrad: pixel count %lld exceeds 2^31", p.M);
   const int KP = d->dtype == VFD_BF16 ? 32 : 16;
-  const long long tiles = (long long)((p.Cs + 127) / 128) * ((p.ncols + 127) / 128);
-  long long nsplit = 768 / tiles;   // one round of 3 resident workgroups per CU
+  static const int force_tile = getenv("VFD_WGRAD_TILE") ? atoi(getenv("VFD_WGRAD_TILE")) : 0;   // tuning: 1 = 128x128, 2 = 256x128, 3 = 128x256
+  const int shape = force_tile ? force_tile : (p.Cs >= 256 ? 2 : ((p.Cs > 64 && p.ncols >= 256) ? 3 : 1));
+  const bool wide = shape != 1;
+  g.tr = shape == 2 ? 256 : 128;
+  g.tc = shape == 3 ? 256 : 128;
+  const long long tiles = (long long)((p.Cs + g.tr - 1) / g.tr) * ((p.ncols + g.tc - 1) / g.tc);
+  long long nsplit = (wide ? 512 : 768) / tiles;   // one round of 2 (8 waves) or 3 (4 waves) resident workgroups per CU
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit > 1024) nsplit = 1024;
@@ -313,12 +335,18 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   g.p.S = d->transposed ? x : dy;
   g.p.G = d->transposed ? dy : x;
   g.p.ws = reinterpret_cast<float*>(ws);
-  dim3 grid((g.p.ncols + 127) / 128, (g.p.Cs + 127) / 128, g.nsplit);
+  dim3 grid((g.p.ncols + g.tc - 1) / g.tc, (g.p.Cs + g.tr - 1) / g.tr, g.nsplit);
   VFD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, "wgrad: grid too large");
-  if (d->dtype == VFD_BF16)
-    hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, as_stream(stream), g.p);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 3>), grid, dim3(256), 0, as_stream(stream), g.p);
+  hipStream_t st = as_stream(stream);
+  if (d->dtype == VFD_BF16) {
+    if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
+    else if (g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 4>), grid, dim3(512), 0, st, g.p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 2>), grid, dim3(256), 0, st, g.p);
+  } else {
+    if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
+    else if (g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 2, 4>), grid, dim3(512), 0, st, g.p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 2, 2>), grid, dim3(256), 0, st, g.p);
+  }
   VFD_CHECK_LAUNCH("conv_wgrad");
   return VFD_OK;
 }
