@@ -166,11 +166,28 @@ __global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long ro
 }
 
 // ---- forward apply --------------------------------------------------------------------------------------------
-template <typename T>
+// The three streaming kernels below are templated on the activation (a runtime switch inside the unrolled channel
+// loop is replicated, branches included, per element) and walk ROWS_U rows per thread and iteration with all loads
+// issued before the first use: they are pure HBM streams and need the loads in flight, not the arithmetic.
+constexpr int ROWS_U = 4;
+template <int ACT> __device__ __forceinline__ float act_c(float x, float slope) {
+  if constexpr (ACT == VFD_ACT_LRELU) return x > 0.f ? x : x * slope;
+  else if constexpr (ACT == VFD_ACT_SIGMOID) return 1.f / (1.f + __expf(-x));
+  else if constexpr (ACT == VFD_ACT_TANH) return tanhf(x);
+  else return x;
+}
+template <int ACT> __device__ __forceinline__ float act_grad_in_c(float x, float slope) {
+  if constexpr (ACT == VFD_ACT_LRELU) return x > 0.f ? 1.f : slope;
+  else if constexpr (ACT == VFD_ACT_SIGMOID) { const float y = 1.f / (1.f + __expf(-x)); return y * (1.f - y); }
+  else if constexpr (ACT == VFD_ACT_TANH) { const float y = tanhf(x); return 1.f - y * y; }
+  else return 1.f;
+}
+
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int TX,
                                                          long long rpb, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, int act, float slope) {
+                                                         const float* __restrict__ beta, float slope) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
@@ -187,22 +204,30 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   const long long rbeg = (long long)blockIdx.y * rpb;
   long long rend = rbeg + rpb;
   if (rend > rows) rend = rows;
-  for (long long r = rbeg + ty; r < rend; r += TY) {
-    float v[8];
-    load8(x + r * Cp + g * 8, v);
+  for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
+    float v[ROWS_U][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (g * 8 + k < C) ? act_apply(v[k] * sc[k] + sf[k], act, slope) : 0.f;
-    store8(y + r * Cp + g * 8, v);
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+      load8(x + (ru < rend ? ru : r) * Cp + g * 8, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[u][k] = (g * 8 + k < C) ? act_c<ACT>(v[u][k] * sc[k] + sf[k], slope) : 0.f;
+      if (ru < rend) store8(y + ru * Cp + g * 8, v[u]);
+    }
   }
 }
 
 // ---- backward reduce: partial sums of g = dy*act'(z) and g*xhat per channel ---------------------------------------
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  float* __restrict__ part, long long rows, int C, int TX,
                                                                  long long rpb, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, int act, float slope) {
+                                                                 const float* __restrict__ beta, float slope) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
@@ -221,15 +246,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
     const long long rbeg = (long long)blockIdx.y * rpb;
     long long rend = rbeg + rpb;
     if (rend > rows) rend = rows;
-    for (long long r = rbeg + ty; r < rend; r += TY) {
-      float v[8], d[8];
-      load8(x + r * Cp + g * 8, v);
-      load8(dy + r * Cp + g * 8, d);
+    for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
+      float v[ROWS_U][8], d[ROWS_U][8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float xh = (v[k] - mu[k]) * rs[k];
-        const float gz = d[k] * act_grad_from_in(xh * ga[k] + be[k], act, slope);
-        sg[k] += gz; sgx[k] += gz * xh;
+      for (int u = 0; u < ROWS_U; ++u) {
+        const long long ru = r + (long long)u * TY;
+        const long long rc = ru < rend ? ru : r;
+        load8(x + rc * Cp + g * 8, v[u]);
+        load8(dy + rc * Cp + g * 8, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < ROWS_U; ++u) {      // rows are added in the same order as an un-unrolled walk
+        if (r + (long long)u * TY < rend) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float xh = (v[u][k] - mu[k]) * rs[k];
+            const float gz = d[u][k] * act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
+            sg[k] += gz; sgx[k] += gz * xh;
+          }
+        }
       }
     }
   }
@@ -275,12 +310,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                                long long rows, int C, int TX, long long rpb,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               int act, float slope, const float* __restrict__ dgamma,
+                                                               float slope, const float* __restrict__ dgamma,
                                                                const float* __restrict__ dbeta) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
@@ -299,21 +334,50 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   const long long rbeg = (long long)blockIdx.y * rpb;
   long long rend = rbeg + rpb;
   if (rend > rows) rend = rows;
-  for (long long r = rbeg + ty; r < rend; r += TY) {
-    float v[8], d[8];
-    load8(x + r * Cp + g * 8, v);
-    load8(dy + r * Cp + g * 8, d);
+  for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
+    float v[ROWS_U][8], d[ROWS_U][8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float xh = (v[k] - mu[k]) * rs[k];
-      const float gz = d[k] * act_grad_from_in(xh * ga[k] + be[k], act, slope);
-      d[k] = ga[k] * rs[k] * (gz - c1[k] - xh * c2[k]);
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+      const long long rc = ru < rend ? ru : r;
+      load8(x + rc * Cp + g * 8, v[u]);
+      load8(dy + rc * Cp + g * 8, d[u]);
     }
-    store8(dx + r * Cp + g * 8, d);
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v[u][k] - mu[k]) * rs[k];
+        const float gz = d[u][k] * act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
+        d[u][k] = ga[k] * rs[k] * (gz - c1[k] - xh * c2[k]);
+      }
+      if (ru < rend) store8(dx + ru * Cp + g * 8, d[u]);
+    }
   }
 }
 
 }  // namespace
+
+// launch M(T, ACT) for the runtime (dtype, act) pair
+#define BN_ACT_DISPATCH(M)                                                                  \
+  do {                                                                                      \
+    if (dtype == VFD_BF16) {                                                                \
+      switch (act) {                                                                        \
+        case VFD_ACT_LRELU: M(bf16_t, VFD_ACT_LRELU); break;                                \
+        case VFD_ACT_SIGMOID: M(bf16_t, VFD_ACT_SIGMOID); break;                            \
+        case VFD_ACT_TANH: M(bf16_t, VFD_ACT_TANH); break;                                  \
+        default: M(bf16_t, VFD_ACT_NONE); break;                                            \
+      }                                                                                     \
+    } else {                                                                                \
+      switch (act) {                                                                        \
+        case VFD_ACT_LRELU: M(float, VFD_ACT_LRELU); break;                                 \
+        case VFD_ACT_SIGMOID: M(float, VFD_ACT_SIGMOID); break;                             \
+        case VFD_ACT_TANH: M(float, VFD_ACT_TANH); break;                                   \
+        default: M(float, VFD_ACT_NONE); break;                                             \
+      }                                                                                     \
+    }                                                                                       \
+  } while (0)
 
 extern "C" size_t vfd_bn_workspace(int64_t rows, int C) {
   (void)rows;
@@ -353,10 +417,9 @@ extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t row
   VFD_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_act_forward: bad arguments");
   const Tiling t = make_tiling(rows, C, 8192);
   dim3 grid(t.gx, t.gy);
-  if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
-  else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+#define BN_FWD(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
+  BN_ACT_DISPATCH(BN_FWD);
+#undef BN_FWD
   VFD_CHECK_LAUNCH("bn_act_forward");
   return VFD_OK;
 }
@@ -370,19 +433,17 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
   dim3 grid(t.gx, t.gy);
   float* part = reinterpret_cast<float*>(ws);
   hipStream_t st = as_stream(stream);
-  if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(bn_act_bwd_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
-  else
-    hipLaunchKernelGGL(bn_act_bwd_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, act, slope);
+#define BN_BWD_P(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
+  BN_ACT_DISPATCH(BN_BWD_P);
+#undef BN_BWD_P
   VFD_CHECK_LAUNCH("bn_act_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, part, t.gy, C, dgamma, dbeta, dgamma_acc, dbeta_acc);
   VFD_CHECK_LAUNCH("bn_bwd_finalize");
   const Tiling ta = make_tiling(rows, C, 8192);
   dim3 grid2(ta.gx, ta.gy);
-  if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, grid2, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, act, slope, dgamma, dbeta);
-  else
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, grid2, dim3(256), 0, st, (const float*)x, (const float*)dy, (float*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, act, slope, dgamma, dbeta);
+#define BN_BWD_A(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, ACT_>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)dy, (T_*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, dgamma, dbeta)
+  BN_ACT_DISPATCH(BN_BWD_A);
+#undef BN_BWD_A
   VFD_CHECK_LAUNCH("bn_act_bwd_apply");
   return VFD_OK;
 }
