@@ -7,6 +7,7 @@
 // owns ONE granule (8 channels, 16/32 bytes) and walks rows, so per-channel parameters are loaded once.
 // Reductions are two-stage and deterministic: workgroup partials in a workspace, then a finalize kernel.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -14,22 +15,33 @@ struct Tiling {
   int TX, TY, gx, gy;
   long long rows_per_block;
 };
-static Tiling make_tiling(long long rows, int C, int max_gy) {
+// rows_per_thread: how many rows of its 8-channel granule a thread walks (streaming kernels: ROWS_U, one unrolled pass;
+// fewer when that leaves under ~16 workgroups per CU, so that small tensors still fill the chip and large ones end
+// without a long tail)
+static Tiling make_tiling(long long rows, int C, int max_blocks, int rows_per_thread = 8) {
   Tiling t;
   const int GR = cpad(C) >> 3;
   int tx = 1;
   while (tx < GR && tx < 256) tx <<= 1;
   t.TX = tx; t.TY = 256 / tx;
   t.gx = (GR + tx - 1) / tx;
-  long long gy = (rows + (long long)t.TY * 8 - 1) / ((long long)t.TY * 8);
-  const long long cap = max_gy / t.gx > 0 ? max_gy / t.gx : 1;
+  long long gy = (rows + (long long)t.TY * rows_per_thread - 1) / ((long long)t.TY * rows_per_thread);
+  long long cap = max_blocks / t.gx > 0 ? max_blocks / t.gx : 1;
+  if (cap > 65535) cap = 65535;
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
   t.gy = (int)gy;
   t.rows_per_block = (rows + gy - 1) / gy;
   return t;
 }
-constexpr int BN_MAX_BLOCKS = 1024;  // partial workgroups per reduction
+// streaming kernels: a fixed number of resident workgroups that each walk many rows — the per-workgroup preamble (a
+// dependent chain of per-channel parameter loads) costs about as much as streaming 8 rows, so short-lived workgroups
+// lose more to it than they gain in balance (measured: 16 K workgroups of 1-2 rows per thread ran the step 20 % slower)
+static Tiling make_stream_tiling(long long rows, int C) {
+  static const int nb = getenv("VFD_BN_STREAM_BLOCKS") ? atoi(getenv("VFD_BN_STREAM_BLOCKS")) : 512;
+  return make_tiling(rows, C, nb, 4);
+}
+constexpr int BN_MAX_BLOCKS = 2048;  // partial workgroups per reduction
 
 // ---- statistics: per-workgroup (count, mean, M2) per channel ----------------------------------------------
 template <typename T>
@@ -415,7 +427,7 @@ extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t row
                                   const float* gamma, const float* beta, int act, float slope, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_forward: bad dtype");
   VFD_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_act_forward: bad arguments");
-  const Tiling t = make_tiling(rows, C, 8192);
+  const Tiling t = make_stream_tiling(rows, C);
   dim3 grid(t.gx, t.gy);
 #define BN_FWD(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
   BN_ACT_DISPATCH(BN_FWD);
@@ -429,7 +441,8 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
                                    float* dbeta, float* dgamma_acc, float* dbeta_acc, void* ws, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_backward: bad dtype");
   VFD_REQUIRE(x && dy && dx && mean && rstd && dgamma && dbeta && ws && rows > 0 && C > 0, "bn_act_backward: bad arguments");
-  const Tiling t = make_tiling(rows, C, BN_MAX_BLOCKS);
+  static const int pnb = getenv("VFD_BN_PART_BLOCKS") ? atoi(getenv("VFD_BN_PART_BLOCKS")) : 512;
+  const Tiling t = make_tiling(rows, C, pnb < BN_MAX_BLOCKS ? pnb : BN_MAX_BLOCKS);
   dim3 grid(t.gx, t.gy);
   float* part = reinterpret_cast<float*>(ws);
   hipStream_t st = as_stream(stream);
@@ -439,7 +452,7 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
   VFD_CHECK_LAUNCH("bn_act_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, part, t.gy, C, dgamma, dbeta, dgamma_acc, dbeta_acc);
   VFD_CHECK_LAUNCH("bn_bwd_finalize");
-  const Tiling ta = make_tiling(rows, C, 8192);
+  const Tiling ta = make_stream_tiling(rows, C);
   dim3 grid2(ta.gx, ta.gy);
 #define BN_BWD_A(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T_, ACT_>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)dy, (T_*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, dgamma, dbeta)
   BN_ACT_DISPATCH(BN_BWD_A);
