@@ -232,33 +232,55 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
     }
 }
 
-// dw[a][b][t] = beta*dw + sum_z ws[z][a][t*Cbp + b].  64 elements x 4 split-lanes per workgroup: consecutive
-// threads read consecutive slab columns (coalesced), every split-lane folds a quarter of the slabs, LDS sums the
-// lanes in a fixed order (bitwise reproducible).
+// dw[a][b][t] = beta*dw + sum_z ws[z][a][t*Cbp + b].  A thread owns 4 consecutive slab columns (one float4 per slab,
+// 1 KiB per wave-load; Cbp is a multiple of 8, so the four share a tap); 64 quads x 4 split-lanes per workgroup: every
+// split-lane folds a quarter of the slabs with 4 loads in flight, LDS sums the lanes in a fixed order (bitwise
+// reproducible), and the sums go to the torch layout.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B,
                                                            int T, int Bp, int nsplit, float beta) {
-  const long long total = (long long)A * T * B;
+  const int ncols = T * Bp;
+  const int qpr = ncols >> 2;                      // column quads per filter row
+  const long long nquads = (long long)A * qpr;
   const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
-  const long long idx = (long long)blockIdx.x * 64 + el;
-  const size_t ncols = (size_t)T * Bp;
+  const long long quad = (long long)blockIdx.x * 64 + el;
   const size_t slab = (size_t)A * ncols;
-  float s = 0.f;
-  int a = 0, b = 0, t = 0;
-  if (idx < total) {
-    b = (int)(idx % B);
-    const long long at = idx / B;
-    t = (int)(at % T);
-    a = (int)(at / T);
-    const size_t off = (size_t)a * ncols + (size_t)t * Bp + b;
-    for (int z = zl; z < nsplit; z += 4) s += ws[z * slab + off];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int a = 0, col = 0;
+  if (quad < nquads) {
+    a = (int)(quad / qpr);
+    col = (int)(quad - (long long)a * qpr) << 2;
+    const float* src = ws + (size_t)a * ncols + col;
+    int z = zl;
+    for (; z + 12 < nsplit; z += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)z * slab);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)(z + 4) * slab);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(z + 8) * slab);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)(z + 12) * slab);
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; z < nsplit; z += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (size_t)z * slab);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  __shared__ float sh[4][64];
+  __shared__ float4 sh[4][64];
   sh[zl][el] = s;
   __syncthreads();
-  if (zl == 0 && idx < total) {
-    s = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
-    float* dst = dw + ((size_t)a * B + b) * T + t;
-    *dst = (beta != 0.f) ? beta * (*dst) + s : s;
+  if (zl == 0 && quad < nquads) {
+    const float4 p0 = sh[0][el], p1 = sh[1][el], p2 = sh[2][el], p3 = sh[3][el];
+    const float r[4] = {((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                        ((p0.w + p1.w) + p2.w) + p3.w};
+    const int t = col / Bp, b0 = col - t * Bp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (b0 + k < B) {
+        float* dst = dw + ((size_t)a * B + b0 + k) * T + t;
+        *dst = (beta != 0.f) ? beta * (*dst) + r[k] : r[k];
+      }
+    }
   }
 }
 
@@ -356,8 +378,8 @@ extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* d
   int rc = make_geom(d, g);
   if (rc != VFD_OK) return rc;
   VFD_REQUIRE(ws && dw, "wgrad_reduce: null pointer");
-  const long long total = (long long)g.A * g.T * g.B;
-  const long long blocks = (total + 63) / 64;
+  const long long nquads = (long long)g.A * ((g.T * g.p.Cgp) >> 2);
+  const long long blocks = (nquads + 63) / 64;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta);
   VFD_CHECK_LAUNCH("wgrad_reduce");
