@@ -106,6 +106,14 @@ int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, 
  * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
 int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes);
 
+/* y = (conv(x, packed) + bias) * act'(mul_src), mul_src a tensor of y's shape and dtype holding the OUTPUT of an
+ * activation (LeakyReLU / Sigmoid / Tanh, derivative taken from the output).  This is the data gradient of a layer
+ * whose input was produced by a conv with a fused activation (nn.Sequential(Conv, LeakyReLU, Conv, ...),
+ * models/ganomaly.py:39-46): the producer's activation gradient rides in this kernel's epilogue instead of a
+ * separate read-read-write pass.  No statistics, no split-K, no workspace. */
+int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
+                         const void* mul_src, int mul_act, float mul_slope, void* stream);
+
 /* Name of the kernel vfd_conv_forward() dispatches this layer to ("conv_igemm<bf16,256c_x_128p>", "conv_cin8<bf16>",
  * "convt_thin<bf16>", ...), NUL-terminated into buf[n]: what the profiler rows of bench.py and profiles/ are keyed
  * on, so that they follow the dispatch rules instead of restating them. */

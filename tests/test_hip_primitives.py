@@ -111,6 +111,45 @@ def test_conv_fused_act_and_stats(dt, dev):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_sequential_activation_gradient_handover(dt, dev):
+    """Conv -> act -> Conv inside one Sequential: the consumer's data gradient carries the producer's activation gradient
+    (vfd_conv_forward_mul) and the producer skips its act_backward pass; gradients must equal torch's, through the
+    LDS-transposed epilogue (64 channels), the direct one (24 channels) and a transposed consumer."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F
+    torch.manual_seed(5)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(5, 64, 4, 2, 1, bias=False), torch.nn.LeakyReLU(0.2),
+                              torch.nn.Conv2d(64, 24, 3, 1, 1), torch.nn.Tanh(),
+                              torch.nn.ConvTranspose2d(24, 72, 4, 2, 1, bias=False), torch.nn.Sigmoid(),
+                              torch.nn.Conv2d(72, 8, 1, 1, 0))
+    mine = vnn.Sequential(vnn.Conv2d(5, 64, 4, 2, 1, bias=False), vnn.LeakyReLU(0.2), vnn.Conv2d(64, 24, 3, 1, 1), vnn.Tanh(),
+                          vnn.ConvTranspose2d(24, 72, 4, 2, 1, bias=False), vnn.Sigmoid(), vnn.Conv2d(72, 8, 1, 1, 0))
+    if dt == torch.bfloat16:
+        with torch.no_grad():
+            for prm in ref.parameters():
+                prm.copy_(prm.bfloat16().float())
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev)
+    x = _rand((3, 5, 12, 10), 21)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    gy = _rand(tuple(yr.shape), 22)
+    yr.backward(gy)
+    xd = x.to(dev).requires_grad_()
+    yc = mine(F.to_cl(xd, dt))
+    y = yc.to_torch()
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    tol = TOL[dt] * (2 if dt == torch.bfloat16 else 5)     # three stacked layers
+    assert relerr(y, yr) < tol
+    assert relerr(xd.grad, xr.grad) < tol, relerr(xd.grad, xr.grad)
+    for (n, pm), pr in zip(mine.named_parameters(), ref.parameters()):
+        assert relerr(pm.grad, pr.grad) < tol, (n, relerr(pm.grad, pr.grad))
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape,act,slope", [((4, 21, 3, 5, 7), 1, 0.2), ((6, 8, 1, 9, 9), 1, 0.0), ((3, 130, 2, 4, 4), 1, 64.0),
                                              ((16, 40), 1, 0.0), ((2, 5, 2, 3, 3), 0, 0.0), ((2, 5, 2, 3, 3), 3, 0.0)])
 def test_bn_act(shape, act, slope, dt, dev):

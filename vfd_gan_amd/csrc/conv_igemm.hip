@@ -37,6 +37,9 @@ struct ConvP {
   int ksplit;   // >1: K range split over blockIdx.z, raw f32 partial tiles go to ws[ksplit][M][Cop]
   float* ws;
   int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
+  const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape): activation gradient of the producer layer
+  int mul_act;
+  float mul_slope;
 };
 
 struct DimClass {  // per-dimension description of the taps of one output class
@@ -420,6 +423,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
         } else {
           if (opix[j] >= 0 && c < p.Cop) {
             T* dst = yg + opix[j] + c;
+            if (p.mul_src != nullptr) {
+              const T* ms = reinterpret_cast<const T*>(p.mul_src) + opix[j] + c;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(Elem<T>::ld(ms + r), p.mul_act, p.mul_slope);
+            }
             if constexpr (sizeof(T) == 2) {
               uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
               *reinterpret_cast<uint2*>(dst) = o;
@@ -466,7 +474,17 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       uint4 v = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
       if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       const long long off = orow[row];
-      if (off >= 0 && cok) *reinterpret_cast<uint4*>(yg + off + n0 + c * 8) = v;
+      if (off >= 0 && cok) {
+        if (p.mul_src != nullptr) {
+          float f[8], m[8];
+          load8(reinterpret_cast<const bf16_t*>(&v), f);
+          load8(reinterpret_cast<const bf16_t*>(p.mul_src) + off + n0 + c * 8, m);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul_act, p.mul_slope);
+          store8(reinterpret_cast<bf16_t*>(&v), f);
+        }
+        *reinterpret_cast<uint4*>(yg + off + n0 + c * 8) = v;
+      }
     }
   }
   if (want_stats) {
@@ -526,7 +544,7 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   if (mb <= 0) return VFD_OK;
   if (maxM >= 0x7fffffffLL) { vfd_set_error("conv: %lld output pixels per class exceed 2^31", maxM); return VFD_EINVAL; }
   ConvP q = p;
-  q.ksplit = pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
+  q.ksplit = p.mul_src != nullptr ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
@@ -588,7 +606,8 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
 }
 
 static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
-                         size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream) {
+                         size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream,
+                         const void* mul_src = nullptr, int mul_act = 0, float mul_slope = 0.f) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
   vfd_conv_desc dn = *d_in;
   if (dn.transposed) {
@@ -610,7 +629,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   }
   {
     // thin-channel pyramid ends have their own kernels (conv_small.hip); they need no workspace
-    const int h = vfd_conv_small_try(d, x, packed, bias, y, stats != nullptr, ws_query != nullptr, as_stream(stream));
+    const int h = mul_src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats != nullptr, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
     if (h > 0) {
       if (ws_query != nullptr) *ws_query = 0;
@@ -627,6 +646,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   p.Kw = d->kd * d->kh * d->kw * p.Cip;
   p.act = d->act; p.slope = d->slope;
   p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
+  p.mul_src = mul_src; p.mul_act = mul_act; p.mul_slope = mul_slope;
   {
     static const int v = getenv("VFD_IGEMM_VARIANT") ? atoi(getenv("VFD_IGEMM_VARIANT")) : 0;
     p.variant = v;
@@ -674,6 +694,13 @@ extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t
 extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                                 float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
   return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
+                                    const void* mul_src, int mul_act, float mul_slope, void* stream) {
+  VFD_REQUIRE(mul_src != nullptr && ((uintptr_t)mul_src & 15) == 0, "conv_forward_mul: mul_src must be a 16-byte aligned tensor of y's shape");
+  VFD_REQUIRE(mul_act >= VFD_ACT_NONE && mul_act <= VFD_ACT_TANH, "conv_forward_mul: bad activation %d", mul_act);
+  return conv_dispatch(d, x, packed, bias, y, nullptr, 0, nullptr, 0, nullptr, stream, mul_src, mul_act, mul_slope);
 }
 
 // Tuning aid (not part of the public ABI): resident workgroups per CU the runtime grants the main kernels.

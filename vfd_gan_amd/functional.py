@@ -49,10 +49,13 @@ class ClTensor:
     ``C``   logical channels (pad channels t[..., C:] are zero)
     ``nsp`` spatial rank seen by the user: 3 -> (N,C,D,H,W), 2 -> (N,C,H,W), 0 -> (N,C)
     """
-    __slots__ = ("t", "C", "nsp")
+    __slots__ = ("t", "C", "nsp", "fused_act")
 
-    def __init__(self, t, C, nsp):
+    def __init__(self, t, C, nsp, fused_act=None):
         self.t, self.C, self.nsp = t, C, nsp
+        # set by conv(): this block is the output of a conv with a fused activation; a sole consumer may claim the
+        # activation's gradient into its own data-gradient epilogue (see _Conv)
+        self.fused_act = fused_act
 
     @property
     def shape(self):
@@ -320,18 +323,24 @@ def _conv_flops(desc):
     return 2.0 * px * taps * desc.Cin * desc.Cout
 
 
-def _conv_launch(desc, x, packed, bias, out, stats=None):
+def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None):
+    """`mul` = (tensor of out's shape, act, slope): out *= act'(tensor) in the epilogue (vfd_conv_forward_mul)."""
     timer = _TIMER[0]
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = load()
-    need = ctypes.c_size_t()
-    check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
-    ws = torch.empty(need.value, dtype=torch.uint8, device=x.device) if need.value else None
-    check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
-                               ptr(stats), stats.numel() * 4 if stats is not None else 0, ptr(ws), need.value, stream()),
-          "conv_forward")
+    if mul is not None:
+        assert stats is None and tuple(mul[0].shape) == tuple(out.shape) and mul[0].dtype == out.dtype
+        check(lib.vfd_conv_forward_mul(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
+                                       mul[0].data_ptr(), int(mul[1]), float(mul[2]), stream()), "conv_forward_mul")
+    else:
+        need = ctypes.c_size_t()
+        check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
+        ws = torch.empty(need.value, dtype=torch.uint8, device=x.device) if need.value else None
+        check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
+                                   ptr(stats), stats.numel() * 4 if stats is not None else 0, ptr(ws), need.value, stream()),
+              "conv_forward")
     if timer is not None:
         e1.record()
         timer.records.append((_conv_kernel_name(desc, stats), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
@@ -342,7 +351,7 @@ class _Conv(torch.autograd.Function):
     gradient through the same kernel with swapped roles + split-K filter gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, stats):
+    def forward(ctx, x, weight, bias, geom, stats, in_act, out_act):
         (Cin, Cout, k, s, p, out_dhw, transposed, act, slope) = geom
         x = x.contiguous()
         N = x.shape[0]
@@ -359,6 +368,14 @@ class _Conv(torch.autograd.Function):
         ctx.in_dhw = in_dhw
         ctx.has_bias = bias is not None
         ctx.bias_param = bias
+        # activation-gradient hand-over (nn.run_fused only, where the producer's output has exactly one consumer):
+        # `in_act` is the token of the conv+activation that produced x; claiming it means THIS layer's data gradient is
+        # delivered already multiplied by act'(x) (vfd_conv_forward_mul) and the producer skips its act_backward pass.
+        ctx.in_act = None
+        if in_act is not None and ctx.needs_input_grad[0]:
+            in_act["claimed"] = True
+            ctx.in_act = (in_act["act"], in_act["slope"])
+        ctx.out_act = out_act
         ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
         return out
 
@@ -373,7 +390,8 @@ class _Conv(torch.autograd.Function):
         in_dhw = ctx.in_dhw
         T = k[0] * k[1] * k[2]
         rows_out = N * out_dhw[0] * out_dhw[1] * out_dhw[2]
-        if act != _lib.ACT_NONE:  # g = dy * act'(y), from the saved output
+        if act != _lib.ACT_NONE and not (ctx.out_act is not None and ctx.out_act["claimed"]):
+            # g = dy * act'(y), from the saved output (unless the consumer already applied it, see forward)
             g = torch.empty_like(gy)
             check(lib.vfd_act_backward(dtype_code(dt), y.data_ptr(), gy.data_ptr(), g.data_ptr(), rows_out, Cout, act,
                                        slope, stream()), "act_backward")
@@ -385,7 +403,7 @@ class _Conv(torch.autograd.Function):
             packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
             gx = torch.empty_like(x)
             desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
-            _conv_launch(desc, gy, packed, None, gx)
+            _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None)
         if ctx.needs_input_grad[1]:
             desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
@@ -419,11 +437,11 @@ class _Conv(torch.autograd.Function):
                 gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
                 check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, bws.data_ptr(),
                                         stream()), "bias_grad")
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, act=_lib.ACT_NONE, slope=0.0,
-         stats=None):
+         stats=None, claim_act_grad=False):
     """Convolution on a ClTensor.  `weight` is the torch-layout float32 parameter ([Cout,Cin,k..] or, transposed,
     [Cin,Cout,k..]); Linear layers pass a [out,in] matrix with x.nsp == 0."""
     nsp = x.nsp
@@ -449,8 +467,10 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
     if min(out_dhw) <= 0:
         raise RuntimeError("conv: kernel %s does not fit input %s (padding %s)" % (k, in_dhw, p))
     geom = (Cin, Cout, k, s, p, out_dhw, bool(transposed), act, float(slope))
-    out = _Conv.apply(x.t, weight, bias, geom, stats)
-    return ClTensor(out, Cout, nsp)
+    in_act = x.fused_act if claim_act_grad else None
+    out_act = {"claimed": False, "act": act, "slope": float(slope)} if act != _lib.ACT_NONE else None
+    out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act)
+    return ClTensor(out, Cout, nsp, out_act)
 
 
 # ---------------------------------------------------------------------------------------------------------

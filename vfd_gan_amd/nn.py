@@ -39,14 +39,15 @@ def _act_of(m):
 class _ConvMixin:
     _transposed = False
 
-    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None):
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None, claim_act_grad=False):
         _need_cl(x, type(self).__name__)
         if self.groups != 1 or any(d != 1 for d in self.dilation):
             raise NotImplementedError("groups/dilation are not used by the reference nets")
         if self.padding_mode != "zeros":
             raise NotImplementedError("padding_mode %r" % (self.padding_mode,))
         op = self.output_padding if self._transposed else 0
-        return F.conv(x, self.weight, self.bias, self.stride, self.padding, op, self._transposed, act, slope, stats)
+        return F.conv(x, self.weight, self.bias, self.stride, self.padding, op, self._transposed, act, slope, stats,
+                      claim_act_grad)
 
 
 class Conv3d(_ConvMixin, tnn.Conv3d):
@@ -173,18 +174,24 @@ def run_fused(mods, x):
     """Run a list of HIP-backed layers, fusing conv->act into the conv epilogue, BatchNorm->act into one
     normalise+activate pass, and (bf16) conv->BatchNorm statistics into the conv epilogue."""
     i, n = 0, len(mods)
+    fresh_act = False      # x is the (single-consumer) output of a conv with a fused activation of this list
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         if isinstance(m, _CONVS):
+            # x straight out of the previous conv+activation of THIS list has no other consumer: this conv's data
+            # gradient takes that activation's gradient into its epilogue (functional._Conv)
+            kw = {"claim_act_grad": True} if (fresh_act and not isinstance(m, Linear)) else {}
+            fresh_act = False
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
-                x = m(x, act=a[0], slope=a[1])
+                x = m(x, act=a[0], slope=a[1], **kw)
+                fresh_act = not isinstance(m, Linear)
                 i += 2
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and use_epilogue_stats(x):
                 sums = F.new_stats_buffer(m.out_channels, x.t.device)
-                x = m(x, stats=sums)
+                x = m(x, stats=sums, **kw)
                 a = _act_of(mods[i + 2]) if i + 2 < n else None
                 if a is not None:
                     x = nxt(x, act=a[0], slope=a[1], sums=sums)
@@ -193,9 +200,10 @@ def run_fused(mods, x):
                     x = nxt(x, sums=sums)
                     i += 2
                 continue
-            x = m(x)
+            x = m(x, **kw)
             i += 1
             continue
+        fresh_act = False
         if isinstance(m, _BNS):
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
