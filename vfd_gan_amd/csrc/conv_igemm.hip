@@ -466,24 +466,41 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   if constexpr (VIA_LDS) {
     constexpr int CPRW = TILE_C / 8;          // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPRW;            // tile rows per wave-instruction
+    constexpr int NIT = TILE_P / RPW;         // wave-instructions for the whole tile
+    constexpr int U = 4;                      // rows in flight per lane
     const int c = lane % CPRW;
     const bool cok = n0 + c * 8 < p.Cop;
-#pragma unroll 4
-    for (int it = wave; it < TILE_P / RPW; it += NWAVES) {
-      const int row = it * RPW + lane / CPRW, n = row & 15;
-      uint4 v = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
-      if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-      const long long off = orow[row];
-      if (off >= 0 && cok) {
-        if (p.mul_src != nullptr) {
+    const bf16_t* ms = reinterpret_cast<const bf16_t*>(p.mul_src);
+    for (int it0 = wave; it0 < NIT; it0 += U * NWAVES) {
+      long long off[U];
+      uint4 v[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * NWAVES;
+        off[u] = (it < NIT && cok) ? orow[it * RPW + lane / CPRW] : -1;
+      }
+      if (ms != nullptr) {      // the producer's activation output at the same positions: all U loads issued together
+#pragma unroll
+        for (int u = 0; u < U; ++u) mv[u] = *reinterpret_cast<const uint4*>(ms + (off[u] >= 0 ? off[u] + n0 + c * 8 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * NWAVES;
+        const int row = (it < NIT ? it : wave) * RPW + lane / CPRW, n = row & 15;
+        v[u] = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
+        if (n & 1) v[u] = make_uint4(v[u].z, v[u].w, v[u].x, v[u].y);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ms != nullptr) {
           float f[8], m[8];
-          load8(reinterpret_cast<const bf16_t*>(&v), f);
-          load8(reinterpret_cast<const bf16_t*>(p.mul_src) + off + n0 + c * 8, m);
+          load8(reinterpret_cast<const bf16_t*>(&v[u]), f);
+          load8(reinterpret_cast<const bf16_t*>(&mv[u]), m);
 #pragma unroll
           for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul_act, p.mul_slope);
-          store8(reinterpret_cast<bf16_t*>(&v), f);
+          store8(reinterpret_cast<bf16_t*>(&v[u]), f);
         }
-        *reinterpret_cast<uint4*>(yg + off + n0 + c * 8) = v;
+        if (off[u] >= 0) *reinterpret_cast<uint4*>(yg + off[u] + n0 + c * 8) = v[u];
       }
     }
   }
