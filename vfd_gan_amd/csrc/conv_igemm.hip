@@ -37,6 +37,7 @@ struct ConvP {
   int ksplit;   // >1: K range split over blockIdx.z, raw f32 partial tiles go to ws[ksplit][M][Cop]
   float* ws;
   int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
+  int ny, ncls, mbp, xcd_order;   // channel tiles, output classes, pixel tiles rounded up to 8, workgroup order (see kernel)
   const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape): activation gradient of the producer layer
   int mul_act;
   float mul_slope;
@@ -183,9 +184,26 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   const int wave_c0 = (wave % WAVES_C) * (NI * 16);
   const int wave_p0 = (wave / WAVES_C) * (NJ * 16);
 
-  // ---- output class of this workgroup --------------------------------------------------------------
-  int cls = blockIdx.z / p.ksplit;
-  const int ksl = blockIdx.z - cls * p.ksplit;
+  // ---- work item of this workgroup ---------------------------------------------------------------------
+  // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All work items that gather the same
+  // pixel tile - its channel tiles and, for a transposed convolution, its stride^3 output classes, which read the same
+  // input pixels through different taps - are therefore given ids congruent mod 8 and adjacent in dispatch order, so
+  // the re-reads hit that XCD's L2 instead of going back to HBM:  id = ((tile / 8) * group + j) * 8 + tile % 8.
+  const int group = p.ncls * p.ny;
+  int ptile, jitem;
+  if (p.xcd_order) {
+    const int slot = blockIdx.x >> 3;
+    const int tq = slot / group;
+    jitem = slot - tq * group;
+    ptile = tq * 8 + (blockIdx.x & 7);
+  } else {
+    jitem = blockIdx.x / p.mbp;
+    ptile = blockIdx.x - jitem * p.mbp;
+  }
+  int cls = jitem / p.ny;
+  const int ytile = jitem - cls * p.ny;
+  const int cls_id = cls;
+  const int ksl = blockIdx.z;
   const int rw = p.transposed ? cls % p.sw : 0;
   if (p.transposed) cls /= p.sw;
   const int rh = p.transposed ? cls % p.sh : 0;
@@ -195,9 +213,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   const DimClass dh = make_dim(p.transposed, rh, p.kh, p.sh, p.ph, p.Ho);
   const DimClass dw = make_dim(p.transposed, rw, p.kw, p.sw, p.pw, p.Wo);
   const long long Mcls = (long long)p.N * dd.Q * dh.Q * dw.Q;
-  const long long m0 = (long long)blockIdx.x * TILE_P;
+  const long long m0 = (long long)ptile * TILE_P;
   if (m0 >= Mcls) return;  // uniform per workgroup
-  const int n0 = blockIdx.y * TILE_C;
+  const int n0 = ytile * TILE_C;
   const int ntaps = dd.nk * dh.nk * dw.nk;
   const int Kcls = ntaps * p.Cip;
   const int nsteps_all = (Kcls + BK - 1) / BK;
@@ -505,7 +523,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     }
   }
   if (want_stats) {
-    float* rep = p.stats + (size_t)((blockIdx.x + blockIdx.z) % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    float* rep = p.stats + (size_t)((ptile + cls_id) % VFD_STATS_REPLICAS) * 2 * p.Cop;
     for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
       const int which = t / TILE_C, cl = t - which * TILE_C;
       float v = 0.f;
@@ -565,8 +583,14 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
-  dim3 grid((unsigned)mb, (unsigned)((p.Cout + TILE_C - 1) / TILE_C), (unsigned)(ncls * q.ksplit));
-  if (grid.y > 65535u || grid.z > 65535u) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
+  static const bool no_xcd = getenv("VFD_NO_XCD_ORDER") != nullptr;
+  q.ny = (p.Cout + TILE_C - 1) / TILE_C;
+  q.ncls = ncls;
+  q.xcd_order = (no_xcd || mb < 16) ? 0 : 1;     // few pixel tiles: the padding to a multiple of 8 would only add idle workgroups
+  q.mbp = q.xcd_order ? (int)((mb + 7) / 8 * 8) : (int)mb;
+  const long long nwg = (long long)q.mbp * q.ny * ncls;
+  if (nwg >= 0x7fffffffLL || q.ksplit > 65535) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
+  dim3 grid((unsigned)nwg, 1, (unsigned)q.ksplit);
   hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
   if (q.ksplit > 1) {
