@@ -28,6 +28,7 @@ struct WgP {
   long long M;                  // N*Qd*Qh*Qw
   long long chunkM;             // pixels per split (multiple of the K step)
   FastDiv fQw, fQh, fQd;        // pixel index -> (n, qd, qh, qw) without integer division
+  int ntx, nty, nsplit, xcd_order;   // column tiles, row tiles, pixel splits; workgroup order (see kernel)
 };
 
 // Tile geometry: [KP pixel rows][128 channels], rows of ROWB bytes = CPR 16-byte chunks, no padding (the tiles are
@@ -133,9 +134,24 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr0 = (wave % WR) * 64, wc0 = (wave / WR) * 64;
-  const int r0 = blockIdx.y * TR;     // first S channel of this tile
-  const int nb0 = blockIdx.x * TC;    // first flattened column of this tile
-  const long long mbeg = (long long)blockIdx.z * p.chunkM;
+  // Workgroups go round-robin to the 8 XCDs (id % 8).  All tiles of one pixel split read the same S and G pixels, so
+  // a split's tiles get ids congruent mod 8 and adjacent in dispatch order: one L2 fetches that pixel range once.
+  int split, tile;
+  const int ntiles = p.ntx * p.nty;
+  if (p.xcd_order) {
+    const int slot = blockIdx.x >> 3;
+    const int sq = slot / ntiles;
+    tile = slot - sq * ntiles;
+    split = sq * 8 + (blockIdx.x & 7);
+    if (split >= p.nsplit) return;
+  } else {
+    split = blockIdx.x / ntiles;
+    tile = blockIdx.x - split * ntiles;
+  }
+  const int ty_ = tile / p.ntx, tx_ = tile - ty_ * p.ntx;
+  const int r0 = ty_ * TR;     // first S channel of this tile
+  const int nb0 = tx_ * TC;    // first flattened column of this tile
+  const long long mbeg = (long long)split * p.chunkM;
   long long mend = mbeg + p.chunkM;
   if (mend > p.M) mend = p.M;
   const int nsteps = (mbeg < mend) ? (int)((mend - mbeg + KP - 1) / KP) : 0;
@@ -218,7 +234,7 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
   }
 
   // slab store: ws[z][r][col], D[row = r (lane>>4)*4+reg][col = lane&15]
-  float* slab = p.ws + (size_t)blockIdx.z * p.Cs * p.ncols;
+  float* slab = p.ws + (size_t)split * p.Cs * p.ncols;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -357,8 +373,14 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   g.p.S = d->transposed ? x : dy;
   g.p.G = d->transposed ? dy : x;
   g.p.ws = reinterpret_cast<float*>(ws);
-  dim3 grid((g.p.ncols + g.tc - 1) / g.tc, (g.p.Cs + g.tr - 1) / g.tr, g.nsplit);
-  VFD_REQUIRE(grid.y <= 65535u && grid.z <= 65535u, "wgrad: grid too large");
+  static const bool no_xcd = getenv("VFD_NO_XCD_ORDER") != nullptr;
+  g.p.ntx = (g.p.ncols + g.tc - 1) / g.tc;
+  g.p.nty = (g.p.Cs + g.tr - 1) / g.tr;
+  g.p.nsplit = g.nsplit;
+  g.p.xcd_order = (!no_xcd && g.nsplit >= 8) ? 1 : 0;
+  const long long nwg = (long long)g.p.ntx * g.p.nty * (g.p.xcd_order ? (g.nsplit + 7) / 8 * 8 : g.nsplit);
+  VFD_REQUIRE(nwg < 0x7fffffffLL, "wgrad: grid too large");
+  dim3 grid((unsigned)nwg, 1, 1);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VFD_BF16) {
     if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
