@@ -35,6 +35,9 @@ CONV_CASES = [
     # >= 256 channels on the strided side: the 8-wave 256 x 128 filter-gradient tile (partial second tile)
     ("K6_conv2d_k4s2_cout264", (2, 24, 10, 10), 264, 4, 2, 1, 0, False, True),
     ("K6_convT2d_k4s2_cin260", (2, 260, 5, 5), 20, 4, 2, 1, 0, True, False),
+    # <= 64 channels on the strided side with >= 256 filter columns: the 64 x 256 filter-gradient tile (128-byte rows)
+    ("K1_conv3d_k3_64to64", (1, 64, 3, 9, 9), 64, 3, 1, 1, 0, False, True),
+    ("K1_conv3d_k3_40to50", (2, 40, 2, 6, 7), 50, 3, 1, 1, 0, False, False),
     # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients
     ("K6_conv2d_first_3to64", (3, 3, 20, 14), 64, 4, 2, 1, 0, False, True),
     ("K6_conv2d_first_3to40", (2, 3, 18, 22), 40, 4, 2, 1, 0, False, False),

@@ -37,14 +37,20 @@ struct WgP {
 template <typename T> struct WgTraits;
 template <> struct WgTraits<bf16_t> {
   static constexpr int KP = 32;       // pixels per K step
+  static constexpr int SWZ_PERIOD = 8;   // swz(row) depends on row & 7
   static constexpr int ROWB = 256;
-  // ds_read_b64_tr_b16: a half-wave touches 8 pixel rows x 32 B; chunk ^ 2*(row&7) spreads them over all 64 banks
-  __device__ static __forceinline__ int swz(int row) { return 2 * (row & 7); }
+  // ds_read_b64_tr_b16: a half-wave touches 8 pixel rows x 32 B.  Rows of >= 256 B all start on bank 0: chunk ^ 2*(row&7)
+  // spreads the 8 rows over all 64 banks.  128-byte rows alternate between the two halves of the 256-byte bank row, so
+  // the 4 rows of one parity must take 4 different 32-byte slots of their half: chunk ^ 2*((row>>1)&3).
+  template <int ROWB>
+  __device__ static __forceinline__ int swz(int row) { return ROWB >= 256 ? 2 * (row & 7) : 2 * ((row >> 1) & 3); }
 };
 template <> struct WgTraits<float> {
   static constexpr int KP = 16;
+  static constexpr int SWZ_PERIOD = 2;
   static constexpr int ROWB = 512;
-  // ds_read_b32: a half-wave touches 2 pixel rows x 64 B; chunk ^ 4*(row&1) puts them on different bank halves
+  // ds_read_b32: a half-wave touches 2 pixel rows x 64 B; chunk ^ 4*(row&1) puts them on different 64-byte slots
+  template <int ROWB>
   __device__ static __forceinline__ int swz(int row) { return 4 * (row & 1); }
 };
 
@@ -56,7 +62,7 @@ __device__ __forceinline__ bf16x8 frag_tr_bf16(const char* tile, int c0, int lan
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int row = 4 * g + q;
   const int ch = c0 + 4 * pp;
-  const int off = row * ROWB + ((((ch >> 3) ^ WgTraits<bf16_t>::swz(row)) << 4) | ((ch & 4) << 1));
+  const int off = row * ROWB + ((((ch >> 3) ^ WgTraits<bf16_t>::swz<ROWB>(row)) << 4) | ((ch & 4) << 1));
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off + 16 * ROWB));   // row + 16: same row & 7
@@ -84,7 +90,7 @@ template <> struct WgMma<bf16_t> {
 template <> struct WgMma<float> {
   template <int ROWB>
   __device__ static __forceinline__ int off(int px, int c) {
-    return px * ROWB + ((((c >> 2) ^ WgTraits<float>::swz(px)) << 4) | ((c & 3) << 2));
+    return px * ROWB + ((((c >> 2) ^ WgTraits<float>::swz<ROWB>(px)) << 4) | ((c & 3) << 2));
   }
   template <int SROWB, int GROWB>
   __device__ static __forceinline__ void step(const char* st, const char* gt, int r0, int c0, int lane,
@@ -111,7 +117,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // WR x WC waves of 64 x 64 outputs each: tile = 64*WR channels of S x 64*WC flattened columns of G.
-// 2 x 2 (4 waves, 3 workgroups per CU) for narrow layers; 4 x 2 (8 waves, 2 per CU) where S has >= 256 channels and
+// 2 x 2 (4 waves, 3 workgroups per CU) for narrow layers, 1 x 4 (64 x 256) when S has <= 64 channels; 4 x 2 (8 waves, 2 per CU) where S has >= 256 channels and
 // 2 x 4 where it has 65..128: 24 KiB of DMA per 32-pixel step instead of 16 KiB for twice the MFMA work.
 template <typename T, int STAGES, int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad_kernel(const WgP p) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
   constexpr int STAGE_BYTES = S_BYTES + G_BYTES;
   static_assert(S_NT >= 1 && G_NT >= 1 && S_NT * S_RPI * NW == KP && G_NT * G_RPI * NW == KP, "tile shape");
   // the source-side swizzle of a lane must not depend on the instruction index i (row = RPI * (wave + NW * i) + lrow)
-  static_assert((S_RPI * NW) % 8 == 0 && (G_RPI * NW) % 8 == 0, "swizzle period");
+  static_assert((S_RPI * NW) % WgTraits<T>::SWZ_PERIOD == 0 && (G_RPI * NW) % WgTraits<T>::SWZ_PERIOD == 0, "swizzle period");
 
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
 
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
 
   // DMA bookkeeping: lane -> (pixel row within a group, physical slot); logical chunk = slot ^ swz(row)
   const int s_lrow = lane / S_CPR, g_lrow = lane / G_CPR;
-  const int s_chunk = (lane % S_CPR) ^ WgTraits<T>::swz(S_RPI * wave + s_lrow);
-  const int g_chunk = (lane % G_CPR) ^ WgTraits<T>::swz(G_RPI * wave + g_lrow);
+  const int s_chunk = (lane % S_CPR) ^ WgTraits<T>::template swz<SROWB>(S_RPI * wave + s_lrow);
+  const int g_chunk = (lane % G_CPR) ^ WgTraits<T>::template swz<GROWB>(G_RPI * wave + g_lrow);
   const int sc = r0 + s_chunk * VEC;
   const bool sc_ok = sc < p.Csp;
   const int col = nb0 + g_chunk * VEC;
@@ -331,10 +337,11 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   VFD_REQUIRE(p.M < 0x7fffffffLL, "wgrad: pixel count %lld exceeds 2^31", p.M);
   const int KP = d->dtype == VFD_BF16 ? 32 : 16;
   static const int force_tile = getenv("VFD_WGRAD_TILE") ? atoi(getenv("VFD_WGRAD_TILE")) : 0;   // tuning: 1 = 128x128, 2 = 256x128, 3 = 128x256
-  const int shape = force_tile ? force_tile : (p.Cs >= 256 ? 2 : ((p.Cs > 64 && p.ncols >= 256) ? 3 : 1));
-  const bool wide = shape != 1;
-  g.tr = shape == 2 ? 256 : 128;
-  g.tc = shape == 3 ? 256 : 128;
+  // 4 = 64x256 (4 waves): S with <= 64 channels would leave half of a 128-row tile empty
+  const int shape = force_tile ? force_tile : (p.Cs >= 256 ? 2 : (p.ncols >= 256 ? (p.Cs > 64 ? 3 : 4) : 1));
+  const bool wide = shape == 2 || shape == 3;
+  g.tr = shape == 2 ? 256 : (shape == 4 ? 64 : 128);
+  g.tc = (shape == 3 || shape == 4) ? 256 : 128;
   const long long tiles = (long long)((p.Cs + g.tr - 1) / g.tr) * ((p.ncols + g.tc - 1) / g.tc);
   long long nsplit = (wide ? 512 : 768) / tiles;   // one round of 2 (8 waves) or 3 (4 waves) resident workgroups per CU
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
@@ -384,10 +391,12 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   hipStream_t st = as_stream(stream);
   if (d->dtype == VFD_BF16) {
     if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
+    else if (g.tr == 64) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 1, 4>), grid, dim3(256), 0, st, g.p);
     else if (g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 4>), grid, dim3(512), 0, st, g.p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 2>), grid, dim3(256), 0, st, g.p);
   } else {
     if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
+    else if (g.tr == 64) hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 1, 4>), grid, dim3(256), 0, st, g.p);
     else if (g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 2, 4>), grid, dim3(512), 0, st, g.p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, 2, 2>), grid, dim3(256), 0, st, g.p);
   }
