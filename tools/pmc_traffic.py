@@ -19,7 +19,7 @@ def short(name):
         dt = "bf16" if a[0] == "unsigned short" else "f32"
         if m.group(1) == "conv_wgrad_kernel":
             return "conv_wgrad<%s,%dx%d>" % (dt, 64 * int(a[2]), 64 * int(a[3]))
-        tile = {("2", "2"): "128c_x_128p", ("2", "4"): "128c_x_256p", ("4", "2"): "256c_x_128p"}.get((a[1], a[2]))
+        tile = {("2", "2"): "128c_x_128p", ("2", "4"): "128c_x_256p", ("4", "2"): "256c_x_128p", ("4", "4"): "256c_x_256p"}.get((a[1], a[2]))
         if tile is None:
             tile = "%dc_x_256p" % (16 * int(a[3]))
         return "conv_igemm<%s,%s>" % (dt, tile)

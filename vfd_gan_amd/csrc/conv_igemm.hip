@@ -18,6 +18,7 @@
 //     transposed : in = q + c0 - t,  k = k0 + t*s, k0 = (r+p)%s, c0 = (r+p-k0)/s,  out = q*s + r
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   constexpr int NPT = (NP + NWAVES - 1) / NWAVES;
   constexpr int STAGE_BYTES = (TILE_C + TILE_P) * ROWB;
   constexpr int DUMP_OFF = STAGES * STAGE_BYTES;   // 1 KiB sink for the padding DMAs of waves without a real row group
-  static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
+  static_assert(NWAVES == 4 || NWAVES == 8 || NWAVES == 16, "4, 8 or 16 waves per workgroup");
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + 1024];
@@ -383,8 +384,13 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
   constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
-  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64 && TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024;
-  constexpr int OUT_BYTES = VIA_LDS ? TILE_P * TILE_C * 2 : 0;
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES + 1024;
+  // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
+  constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
+                     : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
+  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64 && NH > 0;
+  constexpr int HALF_P = VIA_LDS ? TILE_P / NH : TILE_P;
+  constexpr int OUT_BYTES = VIA_LDS ? HALF_P * TILE_C * 2 : 0;
   static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024, "epilogue LDS exceeds the staging ring");
   // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
@@ -412,7 +418,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   if constexpr (VIA_LDS) {
     for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(m0 + r);
   }
-  auto body = [&](auto actf) {
+  // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
+  // accumulator tile across a store phase); the statistics of all sub-tiles are taken in pass 0
+  auto body = [&](auto actf, auto hc) {
+    constexpr int H = decltype(hc)::value;
+    constexpr int JN = VIA_LDS ? NJ / NH : NJ;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = n0 + wave_c0 + i * 16 + cq;
@@ -425,19 +435,22 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+        const bool emit = j >= H * JN && j < (H + 1) * JN;     // compile-time after unrolling
+        if (!emit && H != 0) continue;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t = acc[i][j][r] + b4[r];
-          if (want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+          if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
           v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
         }
+        if (!emit) continue;
         if constexpr (VIA_LDS) {
           // 8-byte unit u of tile row (pixel) with row & 15 == n sits at slot u ^ n: the 16 rows of one ds_write_b64
           // group land on 16 different bank pairs, and a pixel's 16-byte chunk c is found whole at c ^ (n >> 1)
           const int n = lane & 15;
           uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(smem + (wave_p0 + j * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
+          *reinterpret_cast<uint2*>(smem + ((wave / WAVES_C) * (JN * 16) + (j - H * JN) * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
         } else {
           if (opix[j] >= 0 && c < p.Cop) {
             T* dst = yg + opix[j] + c;
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
           }
         }
       }
-      if (want_stats) {
+      if (H == 0 && want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float a = s1[r], b = s2[r];
@@ -470,22 +483,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       }
     }
   };
-  {
-    const float slope = p.slope;
-    constexpr bool FAST = sizeof(T) == 2;     // bf16 output: v_exp/v_rcp forms are exact to far below half an ulp
-    switch (p.act) {
-      case VFD_ACT_LRELU: body([slope](float t) { return t > 0.f ? t : t * slope; }); break;
-      case VFD_ACT_SIGMOID: body([](float t) { return FAST ? fast_sigmoid(t) : 1.f / (1.f + __expf(-t)); }); break;
-      case VFD_ACT_TANH: body([](float t) { return FAST ? fast_tanh(t) : tanhf(t); }); break;
-      default: body([](float t) { return t; }); break;
-    }
-  }
-  if (VIA_LDS || want_stats) __syncthreads();
-  if constexpr (VIA_LDS) {
+  // store phase of pass h: the rows of pixel half h leave LDS as whole pixel rows, 16 bytes per lane
+  auto store_rows = [&](int h) {
     constexpr int CPRW = TILE_C / 8;          // 16-byte chunks per tile row
     constexpr int RPW = 64 / CPRW;            // tile rows per wave-instruction
-    constexpr int NIT = TILE_P / RPW;         // wave-instructions for the whole tile
-    constexpr int U = 4;                      // rows in flight per lane
+    constexpr int NIT = HALF_P / RPW;         // wave-instructions per pass
+    constexpr int U = NH == 1 ? 4 : 2;        // rows in flight per lane (two passes: half the waves still hold their tile)
     const int c = lane % CPRW;
     const bool cok = n0 + c * 8 < p.Cop;
     const bf16_t* ms = reinterpret_cast<const bf16_t*>(p.mul_src);
@@ -495,7 +498,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int it = it0 + u * NWAVES;
-        off[u] = (it < NIT && cok) ? orow[it * RPW + lane / CPRW] : -1;
+        const int lr = it * RPW + lane / CPRW;               // row of this pass's LDS image = (pixel wave, sub-tile, pixel)
+        const int tr = (lr / (HALF_P / WAVES_P)) * (TILE_P / WAVES_P) + h * (HALF_P / WAVES_P) + lr % (HALF_P / WAVES_P);
+        off[u] = (it < NIT && cok) ? orow[tr] : -1;
       }
       if (ms != nullptr) {      // the producer's activation output at the same positions: all U loads issued together
 #pragma unroll
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int it = it0 + u * NWAVES;
-        const int row = (it < NIT ? it : wave) * RPW + lane / CPRW, n = row & 15;
+        const int row = (it < NIT ? it : wave % NIT) * RPW + lane / CPRW, n = row & 15;
         v[u] = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
         if (n & 1) v[u] = make_uint4(v[u].z, v[u].w, v[u].x, v[u].y);
       }
@@ -520,6 +525,29 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
         }
         if (off[u] >= 0) *reinterpret_cast<uint4*>(yg + off[u] + n0 + c * 8) = v[u];
       }
+    }
+  };
+  auto dispatch_body = [&](auto hc) {
+    const float slope = p.slope;
+    constexpr bool FAST = sizeof(T) == 2;     // bf16 output: v_exp/v_rcp forms are exact to far below half an ulp
+    switch (p.act) {
+      case VFD_ACT_LRELU: body([slope](float t) { return t > 0.f ? t : t * slope; }, hc); break;
+      case VFD_ACT_SIGMOID: body([](float t) { return FAST ? fast_sigmoid(t) : 1.f / (1.f + __expf(-t)); }, hc); break;
+      case VFD_ACT_TANH: body([](float t) { return FAST ? fast_tanh(t) : tanhf(t); }, hc); break;
+      default: body([](float t) { return t; }, hc); break;
+    }
+  };
+  dispatch_body(std::integral_constant<int, 0>());
+  if constexpr (!VIA_LDS) {
+    if (want_stats) __syncthreads();
+  } else {
+    __syncthreads();
+    store_rows(0);
+    if constexpr (NH == 2) {
+      __syncthreads();
+      dispatch_body(std::integral_constant<int, 1>());
+      __syncthreads();
+      store_rows(1);
     }
   }
   if (want_stats) {
@@ -612,9 +640,12 @@ int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_b
     // Cout >= 256; 128c x 256p (8 waves) 540-740 for Cout = 128; the 4-wave 128 x 128 tile 520-690.
     if (variant == 1) return launch_cfg<T, 2, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 128c x 128p, 4 waves
     if (variant == 2) return launch_cfg<T, 2, 2, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);   // ... 128-byte rows
-    if (variant == 5 || (variant == 0 && p.Cout <= 128))
+    if (variant == 5 || ((variant == 0 || variant == 17) && p.Cout <= 128))
       return launch_cfg<T, 2, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                   // 128c x 256p, 8 waves
-    return launch_cfg<T, 4, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                     // 256c x 128p, 8 waves
+    if (variant == 4 || variant == 17) return launch_cfg<T, 4, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 256c x 128p, 8 waves
+    // 256c x 256p, 16 waves (one workgroup per CU), 128-byte rows, 2 stages: the only tile whose DMA bytes per MFMA
+    // cycle (31 B/clk/CU at full MFMA rate) fit under the 54 B/clk/CU the global->LDS path delivers with 128-byte rows
+    return launch_cfg<T, 4, 4, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);
   }
   if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  64 ch x 256 px
   if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  32 ch x 256 px
@@ -721,7 +752,8 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
     return VFD_OK;
   }
   const int c = dn.Cout;   // launch<T>() below
-  const char* tile = c > 128 ? "256c_x_128p" : c > 64 ? "128c_x_256p" : c > 32 ? "64c_x_256p" : c > 16 ? "32c_x_256p" : "16c_x_256p";
+  static const int forced = getenv("VFD_IGEMM_VARIANT") ? atoi(getenv("VFD_IGEMM_VARIANT")) : 0;
+  const char* tile = c > 128 ? ((forced == 4 || forced == 17) ? "256c_x_128p" : "256c_x_256p") : c > 64 ? "128c_x_256p" : c > 32 ? "64c_x_256p" : c > 16 ? "32c_x_256p" : "16c_x_256p";
   snprintf(buf, n, "conv_igemm<%s,%s>", t, tile);
   return VFD_OK;
 }
