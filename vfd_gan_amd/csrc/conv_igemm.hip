@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   static_assert(NWAVES == 4 || NWAVES == 8 || NWAVES == 16, "4, 8 or 16 waves per workgroup");
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
 
-  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + 1024];
+  constexpr int DUMP_BYTES = (NW % NWAVES == 0 && NP % NWAVES == 0) ? 0 : 1024;
+  __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + DUMP_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
   constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
-  constexpr int RING_BYTES = STAGES * STAGE_BYTES + 1024;
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES + DUMP_BYTES;
   // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
   constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
                      : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
