@@ -22,6 +22,21 @@
 
 namespace {
 
+struct DimClass {  // per-dimension description of the taps of one output class
+  int nk;   // number of taps
+  int k0;   // first filter index
+  int ks;   // filter index step
+  int c0;   // input coordinate offset
+  int cs;   // input coordinate step per tap (+1 regular, -1 transposed)
+  int a;    // input coordinate multiplier of q
+  int so;   // output coordinate multiplier of q
+  int r;    // output coordinate offset
+  int Q;    // number of q along this dim
+  FastDiv fq;  // division by Q (pixel index decomposition)
+};
+
+constexpr int DIM_TAB = 8;   // per-dimension output classes with a host-built description (stride <= 8; else built on the device)
+
 struct ConvP {
   const void* x;
   const void* w;
@@ -39,23 +54,14 @@ struct ConvP {
   float* ws;
   int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
   int ny, ncls, mbp, xcd_order;   // channel tiles, output classes, pixel tiles rounded up to 8, workgroup order (see kernel)
+  int dim_tab;           // 1: dims[][] below is valid
+  DimClass dims[3][DIM_TAB];   // [d,h,w][output class r]: built on the host (make_dim_host), so that a workgroup's setup
+                               // is scalar loads instead of ~15 integer divisions (one of them 64-bit) per dimension
   const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape): activation gradient of the producer layer
   int mul_act;
   float mul_slope;
 };
 
-struct DimClass {  // per-dimension description of the taps of one output class
-  int nk;   // number of taps
-  int k0;   // first filter index
-  int ks;   // filter index step
-  int c0;   // input coordinate offset
-  int cs;   // input coordinate step per tap (+1 regular, -1 transposed)
-  int a;    // input coordinate multiplier of q
-  int so;   // output coordinate multiplier of q
-  int r;    // output coordinate offset
-  int Q;    // number of q along this dim
-  FastDiv fq;  // division by Q (pixel index decomposition)
-};
 
 // device-side construction of the magic number (a handful of scalar instructions per workgroup, classes differ per block)
 __device__ __forceinline__ FastDiv dev_fastdiv(uint32_t d) {
@@ -85,6 +91,25 @@ __device__ __forceinline__ DimClass make_dim(int transposed, int r, int k, int s
     d.Q = (O > r) ? (O - r + s - 1) / s : 0;
   }
   d.fq = dev_fastdiv((uint32_t)d.Q);
+  return d;
+}
+
+static DimClass make_dim_host(int transposed, int r, int k, int s, int p, int O) {
+  DimClass d;
+  if (!transposed) {
+    d.nk = k; d.k0 = 0; d.ks = 1; d.c0 = -p; d.cs = 1; d.a = s; d.so = 1; d.r = 0; d.Q = O;
+  } else {
+    d.k0 = (r + p) % s;
+    d.nk = (d.k0 < k) ? (k - d.k0 + s - 1) / s : 0;
+    d.ks = s;
+    d.c0 = (r + p - d.k0) / s;
+    d.cs = -1;
+    d.a = 1;
+    d.so = s;
+    d.r = r;
+    d.Q = (O > r) ? (O - r + s - 1) / s : 0;
+  }
+  d.fq = make_fastdiv((uint32_t)d.Q);
   return d;
 }
 
@@ -211,9 +236,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   const int rh = p.transposed ? cls % p.sh : 0;
   if (p.transposed) cls /= p.sh;
   const int rd = p.transposed ? cls : 0;
-  const DimClass dd = make_dim(p.transposed, rd, p.kd, p.sd, p.pd, p.Do);
-  const DimClass dh = make_dim(p.transposed, rh, p.kh, p.sh, p.ph, p.Ho);
-  const DimClass dw = make_dim(p.transposed, rw, p.kw, p.sw, p.pw, p.Wo);
+  const DimClass dd = p.dim_tab ? p.dims[0][rd] : make_dim(p.transposed, rd, p.kd, p.sd, p.pd, p.Do);
+  const DimClass dh = p.dim_tab ? p.dims[1][rh] : make_dim(p.transposed, rh, p.kh, p.sh, p.ph, p.Ho);
+  const DimClass dw = p.dim_tab ? p.dims[2][rw] : make_dim(p.transposed, rw, p.kw, p.sw, p.pw, p.Wo);
   const long long Mcls = (long long)p.N * dd.Q * dh.Q * dw.Q;
   const long long m0 = (long long)ptile * TILE_P;
   if (m0 >= Mcls) return;  // uniform per workgroup
@@ -720,6 +745,15 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   p.act = d->act; p.slope = d->slope;
   p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
   p.mul_src = mul_src; p.mul_act = mul_act; p.mul_slope = mul_slope;
+  {
+    const int kk[3] = {p.kd, p.kh, p.kw}, ss[3] = {p.sd, p.sh, p.sw}, pp[3] = {p.pd, p.ph, p.pw}, oo[3] = {p.Do, p.Ho, p.Wo};
+    p.dim_tab = 1;
+    for (int i = 0; i < 3; ++i) {
+      const int nr = p.transposed ? ss[i] : 1;
+      if (nr > DIM_TAB) { p.dim_tab = 0; break; }
+      for (int r = 0; r < nr; ++r) p.dims[i][r] = make_dim_host(p.transposed, r, kk[i], ss[i], pp[i], oo[i]);
+    }
+  }
   {
     static const int v = getenv("VFD_IGEMM_VARIANT") ? atoi(getenv("VFD_IGEMM_VARIANT")) : 0;
     p.variant = v;
