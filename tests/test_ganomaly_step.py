@@ -81,6 +81,7 @@ def test_ganomaly_generalised_pyramid_112(dev, tmp_path):
     from vfd_gan_amd import functional as F
     from vfd_oracle import ganomaly as OG
     model, og, od, opt = _build(tmp_path, dev, torch.float32, 1, 2, 112, 8)
+    torch.manual_seed(112)
     x = torch.rand(2, 3, 112, 112) * 2 - 1
     fr, li, lo = og(x)
     pr, ft = od(x)
@@ -92,10 +93,10 @@ def test_ganomaly_generalised_pyramid_112(dev, tmp_path):
     loss = fh.to_torch().mean() + lih.to_torch().pow(2).mean() + loh.to_torch().mean() + ph.to_torch().mean() + fth.to_torch().pow(2).mean()
     loss.backward()
     assert relerr(fh.to_torch(), fr) < 1e-4 and relerr(loh.to_torch(), lo) < 1e-4 and relerr(fth.to_torch(), ft) < 1e-4
-    for (k, p), (_, r) in zip(model.netg.named_parameters(), og.named_parameters()):
-        assert relerr(p.grad, r.grad) < 2e-3, k
-    for (k, p), (_, r) in zip(model.netd.named_parameters(), od.named_parameters()):
-        assert relerr(p.grad, r.grad) < 2e-3, k
+    errs = {k: relerr(p.grad, r.grad) for (k, p), (_, r) in list(zip(model.netg.named_parameters(), og.named_parameters())) +
+            list(zip(model.netd.named_parameters(), od.named_parameters()))}
+    bad = {k: v for k, v in errs.items() if not v < 2e-3}
+    assert not bad, bad
 
 
 def test_graph_replay_equals_eager(dev, tmp_path):

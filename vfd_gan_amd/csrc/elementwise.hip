@@ -96,21 +96,31 @@ __global__ void tt_nsc_to_ncs_kernel(const T* __restrict__ src, T* __restrict__ 
 // ---- filter packing -----------------------------------------------------------------------------------
 // w f32 [A][B][T] -> packed T [R][T][Ccp] ; transpose_ab=0: R=A,Cc=B ; 1: R=B,Cc=A.  One thread per element
 // of the packed block (pad channels written as zero).
+// One workgroup transposes a [64 contracted channels][<= 64 taps] block of one packed row through LDS: the reads walk
+// contiguous taps per channel (the whole block is contiguous when transpose_ab == 0 and T <= 64), the writes 64
+// consecutive channels per tap (128 B of bf16) — instead of one 4-byte gather per packed element.
 template <typename T>
-__global__ void pack_filter_kernel(const float* __restrict__ w, T* __restrict__ out, int A, int B, int Tn, int tr) {
-  const int R = tr ? B : A, Cc = tr ? A : B, Ccp = (Cc + 7) & ~7;
-  const long long total = (long long)R * Tn * Ccp;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Ccp);
-    const long long rt = i / Ccp;
-    const int t = (int)(rt % Tn);
-    const int r = (int)(rt / Tn);
+__global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restrict__ w, T* __restrict__ out, int A, int B, int Tn, int tr) {
+  __shared__ float tile[64][65];
+  const int Cc = tr ? A : B, Ccp = (Cc + 7) & ~7;
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, t0 = blockIdx.z * 64;
+  const int nc = min(64, Cc - c0);                // real channels in this block (<= 0 for a pad-only tail)
+  const int nt = min(64, Tn - t0);
+  for (int i = threadIdx.x; i < 64 * nt; i += 256) {
+    const int c = i / nt, t = i - c * nt;
     float v = 0.f;
-    if (c < Cc) {
-      const int a = tr ? c : r, b = tr ? r : c;
-      v = w[((long long)a * B + b) * Tn + t];
+    if (c < nc) {
+      const int cc = c0 + c;
+      const size_t ab = tr ? (size_t)cc * B + r : (size_t)r * B + cc;
+      v = w[ab * Tn + t0 + t];
     }
-    Elem<T>::st(out + i, v);
+    tile[c][t] = v;
+  }
+  __syncthreads();
+  const int ncp = min(64, Ccp - c0);              // channels to write, padding included
+  for (int i = threadIdx.x; i < 64 * nt; i += 256) {
+    const int t = i >> 6, c = i & 63;
+    if (c < ncp) Elem<T>::st(out + ((size_t)r * Tn + t0 + t) * Ccp + c0 + c, tile[c][t]);
   }
 }
 
@@ -401,11 +411,12 @@ extern "C" int vfd_pack_filter(int dtype, const float* w, void* packed, int A, i
   CHECK_DTYPE(dtype, "pack_filter");
   VFD_REQUIRE(w && packed && A > 0 && B > 0 && T > 0, "pack_filter: bad arguments");
   const int R = transpose_ab ? B : A, Cc = transpose_ab ? A : B;
-  const long long total = (long long)R * T * cpad(Cc);
+  VFD_REQUIRE((cpad(Cc) + 63) / 64 <= 65535 && (T + 63) / 64 <= 65535, "pack_filter: %d channels / %d taps exceed the launch limits", Cc, T);
+  const dim3 grid((unsigned)R, (unsigned)((cpad(Cc) + 63) / 64), (unsigned)((T + 63) / 64));
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), w, (bf16_t*)packed, A, B, T, transpose_ab);
+    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), w, (bf16_t*)packed, A, B, T, transpose_ab);
   else
-    hipLaunchKernelGGL(pack_filter_kernel<float>, dim3(ew_blocks(total)), dim3(EW_THREADS), 0, as_stream(stream), w, (float*)packed, A, B, T, transpose_ab);
+    hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, as_stream(stream), w, (float*)packed, A, B, T, transpose_ab);
   VFD_CHECK_LAUNCH("pack_filter");
   return VFD_OK;
 }

@@ -7,6 +7,8 @@ checkpoint compatibility come from the parent — and overrides only ``forward``
 kernels on a :class:`~vfd_gan_amd.functional.ClTensor` (channels-last, bf16/f32).  There is no torch fallback:
 calling these layers with CPU tensors raises.
 """
+import os
+
 import torch
 import torch.nn as tnn
 
@@ -170,6 +172,9 @@ _CONVS = (Conv3d, Conv2d, ConvTranspose3d, ConvTranspose2d, Linear)
 _BNS = (BatchNorm3d, BatchNorm2d, BatchNorm1d)
 
 
+_NO_HANDOVER = bool(os.environ.get("VFD_NO_ACT_HANDOVER"))    # tuning / bisecting switch
+
+
 def run_fused(mods, x):
     """Run a list of HIP-backed layers, fusing conv->act into the conv epilogue, BatchNorm->act into one
     normalise+activate pass, and (bf16) conv->BatchNorm statistics into the conv epilogue."""
@@ -181,7 +186,7 @@ def run_fused(mods, x):
         if isinstance(m, _CONVS):
             # x straight out of the previous conv+activation of THIS list has no other consumer: this conv's data
             # gradient takes that activation's gradient into its epilogue (functional._Conv)
-            kw = {"claim_act_grad": True} if (fresh_act and not isinstance(m, Linear)) else {}
+            kw = {"claim_act_grad": True} if (fresh_act and not isinstance(m, Linear) and not _NO_HANDOVER) else {}
             fresh_act = False
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
