@@ -141,13 +141,16 @@ int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, flo
  * x is [rows][Cp]; statistics are over rows (biased variance for normalisation, unbiased for running_var).
  * ---------------------------------------------------------------------------------------------- */
 /* partial[blocks][3][Cp] workspace reduction -> mean[Cp], rstd[Cp]; updates running stats when non-NULL:
- * running = (1-momentum)*running + momentum*batch (unbiased var).  ws must hold vfd_bn_workspace() bytes. */
+ * running = (1-momentum)*running + momentum*batch (unbiased var), and *num_batches_tracked += 1 (the counter torch's
+ * BatchNorm keeps next to them; it rides in this launch instead of its own).  ws must hold vfd_bn_workspace() bytes. */
 size_t vfd_bn_workspace(int64_t rows, int C);
 int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float momentum, float* mean,
-                 float* rstd, float* running_mean, float* running_var, void* ws, void* stream);
+                 float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
+                 void* stream);
 /* Same, from the conv epilogue's sum / sum-of-squares buffer (stats[VFD_STATS_REPLICAS][2][Cp]).         */
 int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean,
-                           float* rstd, float* running_mean, float* running_var, void* stream);
+                           float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           void* stream);
 /* y = act((x-mean)*rstd*gamma + beta) */
 int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int act, float slope,

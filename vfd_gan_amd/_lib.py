@@ -46,8 +46,8 @@ SIGNATURES = {
     "vfd_bias_grad_workspace": (c_sz, [c_int]),
     "vfd_bias_grad": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_vp]),
     "vfd_bn_workspace": (c_sz, [c_i64, c_int]),
-    "vfd_bn_stats": (c_int, [c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "vfd_bn_stats_from_sums": (c_int, [c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vfd_bn_stats": (c_int, [c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vfd_bn_stats_from_sums": (c_int, [c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_bn_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

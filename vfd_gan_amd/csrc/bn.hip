@@ -126,7 +126,8 @@ __device__ __forceinline__ void bn_write_stats(int c, double n, double mean, dou
 // One workgroup per 32 channels: 8 part-lanes per channel walk the workgroup partials, Chan-merge in LDS.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, float eps,
                                                           float momentum, float* mean_o, float* rstd_o, float* rmean,
-                                                          float* rvar) {
+                                                          float* rvar, long long* nbt) {
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // BatchNorm.num_batches_tracked
   const int Cp = (C + 7) & ~7;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 __global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long rows, int C, float eps, float momentum,
-                                    float* mean_o, float* rstd_o, float* rmean, float* rvar) {
+                                    float* mean_o, float* rstd_o, float* rmean, float* rvar, long long* nbt) {
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // BatchNorm.num_batches_tracked
   const int Cp = (C + 7) & ~7;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -397,7 +399,7 @@ extern "C" size_t vfd_bn_workspace(int64_t rows, int C) {
 }
 
 extern "C" int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
-                            float* running_mean, float* running_var, void* ws, void* stream) {
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_stats: bad dtype");
   VFD_REQUIRE(x && mean && rstd && ws && rows > 0 && C > 0, "bn_stats: bad arguments");
   const Tiling t = make_tiling(rows, C, BN_MAX_BLOCKS);
@@ -409,16 +411,16 @@ extern "C" int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float
     hipLaunchKernelGGL(bn_partial_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, part, (long long)rows, C, t.TX, t.rows_per_block);
   VFD_CHECK_LAUNCH("bn_partial");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), part, t.gy, C, eps, momentum, mean,
-                     rstd, running_mean, running_var);
+                     rstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
   VFD_CHECK_LAUNCH("bn_finalize");
   return VFD_OK;
 }
 
 extern "C" int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
-                                      float* running_mean, float* running_var, void* stream) {
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   VFD_REQUIRE(stats && mean && rstd && rows > 0 && C > 0, "bn_stats_from_sums: bad arguments");
   hipLaunchKernelGGL(bn_from_sums_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, (long long)rows, C, eps,
-                     momentum, mean, rstd, running_mean, running_var);
+                     momentum, mean, rstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
   VFD_CHECK_LAUNCH("bn_from_sums");
   return VFD_OK;
 }

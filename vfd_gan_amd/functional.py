@@ -478,7 +478,7 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
 # ---------------------------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums):
+    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt):
         lib = load()
         x = x.contiguous()
         rows = x.numel() // x.shape[-1]
@@ -490,11 +490,11 @@ class _BnAct(torch.autograd.Function):
             if sums.numel() < STATS_REPLICAS * 2 * cpad(C):
                 raise RuntimeError("bn_act: statistics buffer too small (use functional.new_stats_buffer)")
             check(lib.vfd_bn_stats_from_sums(sums.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
-                                             ptr(running_mean), ptr(running_var), stream()), "bn_stats_from_sums")
+                                             ptr(running_mean), ptr(running_var), ptr(nbt), stream()), "bn_stats_from_sums")
         else:
             ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
             check(lib.vfd_bn_stats(dtc, x.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
-                                   ptr(running_mean), ptr(running_var), ws.data_ptr(), stream()), "bn_stats")
+                                   ptr(running_mean), ptr(running_var), ptr(nbt), ws.data_ptr(), stream()), "bn_stats")
         y = torch.empty_like(x)
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         check(lib.vfd_bn_act_forward(dtc, x.data_ptr(), y.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), ptr(g_),
@@ -521,15 +521,18 @@ class _BnAct(torch.autograd.Function):
                                       mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
                                       dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ws.data_ptr(), stream()), "bn_act_backward")
         return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
-                dbeta if (beta is not None and db_acc is None) else None, None, None, None, None, None, None, None, None)
+                dbeta if (beta is not None and db_acc is None) else None, None, None, None, None, None, None, None, None, None)
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,
-           sums=None):
+           sums=None, num_batches_tracked=None):
     """Training-mode batch normalisation over all rows of `x` followed by `act`; updates the running statistics
-    in place (momentum rule, unbiased variance) exactly like torch.nn.BatchNormNd.train()."""
+    in place (momentum rule, unbiased variance) exactly like torch.nn.BatchNormNd.train(); `num_batches_tracked`
+    (int64 device scalar) is incremented by the statistics kernel."""
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise TypeError("num_batches_tracked must be an int64 device tensor")
     y = _BnAct.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act),
-                     float(slope), sums)
+                     float(slope), sums, num_batches_tracked)
     return ClTensor(y, x.C, x.nsp)
 
 

@@ -98,11 +98,10 @@ class _BatchNormMixin:
             raise NotImplementedError("eval-mode BatchNorm is off the training hot path (SURVEY.md 8f N2)")
         if self.momentum is None:
             raise NotImplementedError("cumulative-average BatchNorm (momentum=None)")
-        if self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
-        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums)
+        nbt = self.num_batches_tracked if self.track_running_stats else None      # += 1 inside the statistics kernel
+        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt)
 
 
 class BatchNorm3d(_BatchNormMixin, tnn.BatchNorm3d):
