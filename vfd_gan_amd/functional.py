@@ -37,6 +37,11 @@ def cpad(c):
 STATS_REPLICAS = 64  # == VFD_STATS_REPLICAS (include/vfdgan_hip.h)
 
 
+def stats_buffer_numel(C):
+    """Floats in the conv-epilogue statistics buffer of a C-channel output (see new_stats_buffer)."""
+    return STATS_REPLICAS * 2 * cpad(C)
+
+
 def new_stats_buffer(channels, device):
     """Zeroed [STATS_REPLICAS][2][CPAD(C)] float32 buffer for a conv epilogue's BatchNorm partial sums."""
     return torch.zeros(STATS_REPLICAS * 2 * cpad(channels), dtype=torch.float32, device=device)

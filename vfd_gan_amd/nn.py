@@ -179,6 +179,14 @@ def run_fused(mods, x):
     normalise+activate pass, and (bf16) conv->BatchNorm statistics into the conv epilogue."""
     i, n = 0, len(mods)
     fresh_act = False      # x is the (single-consumer) output of a conv with a fused activation of this list
+    # one zero-filled allocation for the statistics buffers of every conv -> BatchNorm pair of the list (one fill
+    # launch instead of one per pair)
+    pool, pool_off = None, 0
+    if use_epilogue_stats(x):
+        need = sum(F.stats_buffer_numel(m.out_channels) for j, m in enumerate(mods[:-1])
+                   if isinstance(m, _CONVS) and not isinstance(m, Linear) and isinstance(mods[j + 1], _BNS) and mods[j + 1].training)
+        if need:
+            pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
@@ -194,7 +202,9 @@ def run_fused(mods, x):
                 i += 2
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and use_epilogue_stats(x):
-                sums = F.new_stats_buffer(m.out_channels, x.t.device)
+                k = F.stats_buffer_numel(m.out_channels)
+                sums = pool.narrow(0, pool_off, k)
+                pool_off += k
                 x = m(x, stats=sums, **kw)
                 a = _act_of(mods[i + 2]) if i + 2 < n else None
                 if a is not None:
