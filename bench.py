@@ -59,7 +59,9 @@ def build_model(args_ns, dtype):
     from vfd_gan_amd.models.ganomaly import Ganomaly
     F.set_compute_dtype(dtype)
     torch.manual_seed(1234)     # identical initial weights on every rank (and broadcast again inside)
-    return Ganomaly(args_ns, None)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the trainer base class announces its save path (reference behaviour):
+        return Ganomaly(args_ns, None)               # stdout carries the ONE JSON line only
 
 
 def host_cores():
