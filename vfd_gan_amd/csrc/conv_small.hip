@@ -7,8 +7,9 @@
 // (a pixel's 8-channel granule, or 8 consecutive channels of a 64..128-channel pixel, IS a fragment lane's 16 bytes)
 // and the filter lives in LDS / registers for the whole kernel.
 //
-//   conv_cin8   regular conv, CPAD(Cin) == 8, kw == 4, kh == 4: one K-step = the 4 taps of one filter row
-//               (4 taps x 8 channels = 32 = K of v_mfma_f32_16x16x32_bf16).  Persistent workgroups, filter in LDS in
+//   conv_cin8   regular conv, CPAD(Cin) == 8, 3..4 x 3..4 filter rows (x up to 4 depth taps): one K-step = the taps of
+//               one filter row (4 taps x 8 channels = 32 = K of v_mfma_f32_16x16x32_bf16; a 3-tap row leaves the 4th
+//               K group zero).  Persistent workgroups, filter in LDS in
 //               fragment order, 64 channels x 32 pixels per wave.
 //   convt_thin  ConvTranspose k4 s2 p1 with Cout <= 4, scatter form: per INPUT pixel the 16 taps x Cout products
 //               D[tap, co] = W[:, co, tap] . x[pixel, :] are one small GEMM (16*Cout rows, K = Cin); the strip's D
@@ -24,11 +25,11 @@ namespace {
 // ============================================================================================================
 struct Cin8P {
   const bf16_t* x;
-  const bf16_t* w;      // packed [Cout][kd*4*4][8]
+  const bf16_t* w;      // packed [Cout][kd*kh*kw][8]
   bf16_t* y;
   const float* bias;
   int N, Di, Hi, Wi, Do, Ho, Wo, Cout, Cop;
-  int kd, sd, sh, sw, pd, ph, pw;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int act;
   float slope;
   FastDiv fWo, fHo, fDo;
@@ -52,9 +53,11 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
   // ---- filter -> LDS, in fragment order: lane (m = lane&15, g) of fragment (ks, i) holds w[i*16+m][ks*4+g][0..7]
   for (int f = tid; f < nks * CIN8_NI * 64; f += 64 * CIN8_WAVES) {
     const int l = f & 63, fi = (f >> 6) % CIN8_NI, ks = (f >> 6) / CIN8_NI;
-    const int co = fi * 16 + (l & 15), tap = ks * 4 + (l >> 4);
+    // K-step ks = (kz, ky) with ky padded to 4 rows, K group = kx padded to 4 taps: absent taps are zero filter rows
+    const int co = fi * 16 + (l & 15), kz = ks >> 2, ky = ks & 3, kx = l >> 4;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (co < p.Cout) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (nks * 4) + tap) * 8);
+    if (co < p.Cout && ky < p.kh && kx < p.kw)
+      v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (p.kd * p.kh * p.kw) + (kz * p.kh + ky) * p.kw + kx) * 8);
     *reinterpret_cast<uint4*>(smem + (size_t)f * 16) = v;
   }
   // bias (zero beyond Cout) behind the filter fragments and the per-wave transpose tiles
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
       id0[j] = (int)od * p.sd - p.pd;
       ih0[j] = (int)oh * p.sh - p.ph;
       const int iw = (int)ow * p.sw - p.pw + g;
-      colok[j] = m < p.M && (unsigned)iw < (unsigned)p.Wi;
+      colok[j] = m < p.M && (unsigned)iw < (unsigned)p.Wi && g < p.kw;
       base[j] = ((((long long)n * p.Di + id0[j]) * p.Hi + ih0[j]) * p.Wi + iw) * 8;
     }
   };
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
       for (int j = 0; j < CIN8_NJ; ++j) {
-        const bool ok = colok[j] && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
+        const bool ok = colok[j] && ky < p.kh && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
         const long long off = ok ? base[j] + ((long long)kz * p.Hi + ky) * p.Wi * 8 : 0;
         braw[ky][j] = *reinterpret_cast<const uint4*>(p.x + off);
         bok |= ok ? 1u << (ky * CIN8_NJ + j) : 0u;
@@ -346,7 +349,7 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
   if (!small_enabled() || d->dtype != VFD_BF16 || want_stats) return 0;
   const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
   if (!d->transposed) {
-    if (Cip != 8 || d->kh != 4 || d->kw != 4 || d->Cout > 16 * CIN8_NI || d->Cout < 17 || d->kd > 4) return 0;
+    if (Cip != 8 || d->kh > 4 || d->kw > 4 || d->kh * d->kw < 9 || d->Cout > 16 * CIN8_NI || d->Cout < 17 || d->kd > 4) return 0;
     const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     if (M >= 0x7fffffffLL / CIN8_TILE * CIN8_TILE || M <= 0) return 0;
     if (query) return 1;
@@ -355,7 +358,7 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
     p.y = reinterpret_cast<bf16_t*>(y); p.bias = bias;
     p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
     p.Cout = d->Cout; p.Cop = Cop;
-    p.kd = d->kd; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
+    p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
     p.act = d->act; p.slope = d->slope;
     p.fWo = make_fastdiv((uint32_t)d->Wo); p.fHo = make_fastdiv((uint32_t)d->Ho); p.fDo = make_fastdiv((uint32_t)d->Do);
     p.M = M;
