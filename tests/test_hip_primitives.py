@@ -38,6 +38,8 @@ CONV_CASES = [
     # <= 64 channels on the strided side with >= 256 filter columns: the 64 x 256 filter-gradient tile (128-byte rows)
     ("K1_conv3d_k3_64to64", (1, 64, 3, 9, 9), 64, 3, 1, 1, 0, False, True),
     ("K1_conv3d_k3_40to50", (2, 40, 2, 6, 7), 50, 3, 1, 1, 0, False, False),
+    # 517 tiles of 128c x 256p on 512 workgroup slots (more than one round of workgroups, XCD-ordered ids)
+    ("K6_conv2d_k1_517tiles", (3, 8, 210, 210), 128, 1, 1, 0, 0, False, True),
     # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients
     ("K6_conv2d_first_3to64", (3, 3, 20, 14), 64, 4, 2, 1, 0, False, True),
     ("K6_conv2d_first_3to40", (2, 3, 18, 22), 40, 4, 2, 1, 0, False, False),
