@@ -18,4 +18,8 @@ def dev():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
+    # every kernel workspace is NaN-filled before use for the whole GPU suite: a partial result that is never written,
+    # or read before it is written, fails the run it happens in instead of hiding behind stale finite bytes
+    from vfd_gan_amd import functional as F
+    F.set_workspace_poison(True)
     return torch.device("cuda", 0)

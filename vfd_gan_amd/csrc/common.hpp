@@ -174,4 +174,21 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// ---- LDS-DMA issued from inline asm ---------------------------------------------------------------------
+// global_load_lds_dwordx4: lane l's 16 bytes at `gsrc` (per-lane source) land at LDS byte address lds_dst + 16*l
+// (wave-uniform destination, passed in M0).  The ring kernels count their DMAs by hand (s_waitcnt vmcnt(N) across a raw
+// s_barrier); issued through __builtin_amdgcn_global_load_lds the compiler ALSO tracks them and, for LDS reads it cannot
+// disambiguate (the ds_read_b64_tr_b16 builtin carries no alias information), emits `s_waitcnt vmcnt(0)` in front of
+// the first read of every K-step, which drains the ring (found by tools/isa_audit.py in every bf16 conv_wgrad
+// instantiation of round 1).  From inline asm the DMA is invisible to that bookkeeping; the "memory" clobber keeps the
+// compiler's own LDS accesses on their side of the statement.  M0 is written in the same statement that reads it
+// (the compiler does not preserve M0 around asm); the audit checks that the kernel has no other use of M0.
+typedef __attribute__((address_space(3))) char lds_char_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(lds_char_t*)p;
+}
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, uint32_t lds_dst_uniform) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -176,9 +176,6 @@ template <> struct Mma<float> {
 // per-lane predicate that zero-fills, but its SOURCE address is per lane).
 __device__ uint4 g_zero_page[4];
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
-
 // Staging: global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 16 tile rows per wave-instruction), STAGES-deep
 // ring, ONE raw s_barrier per K-step, counted vmcnt so that STAGES-2 future steps stay in flight across the barrier.
 // The LDS image is lane-linear per wave-instruction (row = lane/4, 16-byte slot = lane%4), so the bank swizzle of
@@ -270,12 +267,15 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
 
   // filter rows of this thread: group index gw = wave + 4*i (valid while < NW)
-  long long wrow_off[NWT];      // element offset of (row, tap 0, channel 0), or -1
+  // offsets are kept in 16-byte units in 32 bits (Cip, Kw and kc are multiples of the 16-byte granule; the host checks
+  // that both tensors stay below 2^32 granules = 64 GiB): half the registers of 64-bit element offsets
+  constexpr uint32_t NONE = 0xffffffffu;
+  uint32_t wrow_off[NWT];       // granule offset of (row, tap 0, channel 0), or NONE
 #pragma unroll
   for (int i = 0; i < NWT; ++i) {
     const int g = wave + NWAVES * i;
     const int co = n0 + g * RPI + lrow;
-    wrow_off[i] = (g < NW && co < p.Cout) ? (long long)co * p.Kw : -1;
+    wrow_off[i] = (g < NW && co < p.Cout) ? (uint32_t)(((long long)co * p.Kw) / VEC) : NONE;
   }
   // pixel rows of this thread
   int pn[NPT], pid[NPT], pih[NPT], piw[NPT];
@@ -297,40 +297,42 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     }
   }
   // per-tap state (recomputed only when this thread's chunk moves to another tap)
-  long long wtap_off = 0;       // tap index * Cip inside a filter row
-  long long ppix_off[NPT];      // element offset of the gathered input pixel, or -1 (padding / out of range)
+  uint32_t wtap_off = 0;        // tap index * Cip inside a filter row, in granules
+  uint32_t ppix_off[NPT];       // granule offset of the gathered input pixel, or NONE (padding / out of range)
   bool kvalid = false;
   auto enter_tap = [&]() {
     kvalid = (td < dd.nk) && ntaps > 0;
     const int tapidx = ((dd.k0 + td * dd.ks) * p.kh + (dh.k0 + th * dh.ks)) * p.kw + (dw.k0 + tw * dw.ks);
-    wtap_off = (long long)tapidx * p.Cip;
+    wtap_off = (uint32_t)(tapidx * (p.Cip / VEC));
     const int od = td * dd.cs, oh = th * dh.cs, ow = tw * dw.cs;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int id = pid[i] + od, ih = pih[i] + oh, iw = piw[i] + ow;
       const bool ok = kvalid && pn[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                       (unsigned)iw < (unsigned)p.Wi;
-      ppix_off[i] = ok ? (((long long)(pn[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw) * p.Cip : -1;
+      ppix_off[i] = ok ? (uint32_t)((((pn[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw)) * (uint32_t)(p.Cip / VEC) : NONE;
     }
   };
   enter_tap();
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto issue_stage = [&](int stage) {
-    char* wt = smem + stage * STAGE_BYTES;
-    char* pt = wt + TILE_C * ROWB;
+    const uint32_t wt = smem_base + stage * STAGE_BYTES;      // wave-uniform LDS byte addresses
+    const uint32_t pt = wt + TILE_C * ROWB;
 #pragma unroll
     for (int i = 0; i < NWT; ++i) {
       const int g = wave + NWAVES * i;   // wave-uniform
-      const char* src = (kvalid && wrow_off[i] >= 0) ? reinterpret_cast<const char*>(wg + wrow_off[i] + wtap_off + kc) : zero;
-      char* dst = (NW % NWAVES == 0 || g < NW) ? wt + g * 1024 : smem + DUMP_OFF;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      const char* src = (kvalid && wrow_off[i] != NONE)
+                            ? reinterpret_cast<const char*>(wg) + ((size_t)(wrow_off[i] + wtap_off) << 4) + kc * (int)sizeof(T) : zero;
+      const uint32_t dst = (NW % NWAVES == 0 || g < NW) ? wt + g * 1024 : smem_base + DUMP_OFF;
+      dma16_to_lds(src, dst);      // inline asm: see common.hpp
     }
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int g = wave + NWAVES * i;
-      const char* src = (ppix_off[i] >= 0) ? reinterpret_cast<const char*>(xg + ppix_off[i] + kc) : zero;
-      char* dst = (NP % NWAVES == 0 || g < NP) ? pt + g * 1024 : smem + DUMP_OFF;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+      const char* src = (ppix_off[i] != NONE) ? reinterpret_cast<const char*>(xg) + ((size_t)ppix_off[i] << 4) + kc * (int)sizeof(T) : zero;
+      const uint32_t dst = (NP % NWAVES == 0 || g < NP) ? pt + g * 1024 : smem_base + DUMP_OFF;
+      dma16_to_lds(src, dst);
     }
   };
   auto advance_k = [&]() {
@@ -369,7 +371,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
         // s_waitcnt encoding (gfx9+): vmcnt = imm[3:0] | imm[15:14] << 4; expcnt imm[6:4] = 7, lgkmcnt imm[11:8] = 15: no wait
         __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
       }
-      // every wave's step-s DMAs landed AND every wave finished reading the stage the next issue overwrites
+      // every wave's step-s DMAs landed AND every wave finished reading the stage the next issue overwrites: the
+      // barrier itself waits for no counter, so this wave's LDS reads of the previous step are retired explicitly
+      // (conv_wgrad.hip has the same wait; tools/isa_audit.py checks the emitted stream)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       int nstage = stage + STAGES - 1;
@@ -632,6 +637,15 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   const long long mb = (maxM + TILE_P - 1) / TILE_P;
   if (mb <= 0) return VFD_OK;
   if (maxM >= 0x7fffffffLL) { vfd_set_error("conv: %lld output pixels per class exceed 2^31", maxM); return VFD_EINVAL; }
+  {
+    // the kernel addresses both operands in 32-bit counts of 16-byte granules (and input pixels in 31 bits)
+    const long long in_px = (long long)p.N * p.Di * p.Hi * p.Wi;
+    const long long x_gran = in_px * p.Cip / Elem<T>::VEC, w_gran = (long long)p.Cout * p.Kw / Elem<T>::VEC;
+    if (in_px >= 0x7fffffffLL || x_gran >= 0xffffffffLL || w_gran >= 0xffffffffLL) {
+      vfd_set_error("conv: operand too large for 32-bit granule offsets (%lld input pixels)", in_px);
+      return VFD_EINVAL;
+    }
+  }
   ConvP q = p;
   q.ksplit = p.mul_src != nullptr ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;

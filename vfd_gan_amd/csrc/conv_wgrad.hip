@@ -113,8 +113,6 @@ template <> struct WgMma<float> {
 };
 
 __device__ uint4 g_wg_zero_page[4];   // source of every masked 16-byte chunk (see conv_igemm.hip)
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // WR x WC waves of 64 x 64 outputs each: tile = 64*WR channels of S x 64*WC flattened columns of G.
 // 2 x 2 (4 waves, 3 workgroups per CU) for narrow layers, 1 x 4 (64 x 256) when S has <= 64 channels; 4 x 2 (8 waves, 2 per CU) where S has >= 256 channels and
@@ -182,15 +180,16 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
   const T* __restrict__ Gg = reinterpret_cast<const T*>(p.G);
   const char* zero = reinterpret_cast<const char*>(g_wg_zero_page);
 
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   auto issue_stage = [&](int stage, int s) {
-    char* st = smem + stage * STAGE_BYTES;
-    char* gt = st + S_BYTES;
+    const uint32_t st = smem_base + stage * STAGE_BYTES;     // wave-uniform LDS byte addresses
+    const uint32_t gt = st + S_BYTES;
 #pragma unroll
     for (int i = 0; i < S_NT; ++i) {
       const int g = wave + NW * i;
       const long long m = mbeg + (long long)s * KP + g * S_RPI + s_lrow;
       const char* ssrc = (m < mend && sc_ok) ? reinterpret_cast<const char*>(Sg + (size_t)m * p.Csp + sc) : zero;
-      __builtin_amdgcn_global_load_lds((glb_void_t*)ssrc, (lds_void_t*)(st + g * 1024), 16, 0, 0);
+      dma16_to_lds(ssrc, st + g * 1024);
     }
 #pragma unroll
     for (int i = 0; i < G_NT; ++i) {
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
           gsrc = reinterpret_cast<const char*>(Gg + pix * p.Cgp + gch);
         }
       }
-      __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)(gt + g * 1024), 16, 0, 0);
+      dma16_to_lds(gsrc, gt + g * 1024);
     }
   };
 
@@ -227,6 +226,11 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
         constexpr int N = (S_NT + G_NT) * (STAGES - 2);
         __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));   // vmcnt(N)
       }
+      // WAR: the DMAs issued below overwrite the stage read in iteration s-1; `s_barrier` waits for no counter, so every
+      // LDS read of that iteration must have RETURNED before this wave arrives here.  The compiler's own lgkmcnt waits
+      // in front of the consuming MFMAs already guarantee it in every instantiation (tools/isa_audit.py); the explicit
+      // wait makes it independent of how the MFMAs are scheduled.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       int nstage = stage + STAGES - 1;

@@ -7,6 +7,7 @@ wrapped in :class:`ClTensor`, which remembers the logical channel count.  PyTorc
 streams and the autograd tape; no arithmetic of the hot path is done by torch operators.
 """
 import ctypes
+import os
 
 import torch
 
@@ -35,6 +36,26 @@ def cpad(c):
 
 
 STATS_REPLICAS = 64  # == VFD_STATS_REPLICAS (include/vfdgan_hip.h)
+
+# Debug switch (env VFD_POISON_WS=1 or set_workspace_poison): every kernel workspace (split-K slabs of the filter
+# gradient and of few-pixel convolutions, BatchNorm / bias / loss partials) is filled with NaN bit patterns before
+# the kernel that writes it runs.  Workspaces come from torch.empty, i.e. hold stale FINITE data of earlier
+# launches: a slab that is never written, or read before it is written, would otherwise show up as a small
+# deviation (the round-1 observation); poisoned, it turns the result into NaN in one run.
+# The GPU test suite runs with the switch on (tests/conftest.py).
+_POISON_WS = [bool(int(os.environ.get("VFD_POISON_WS", "0") or 0))]
+
+
+def set_workspace_poison(on):
+    _POISON_WS[0] = bool(on)
+
+
+def _workspace(nbytes, device):
+    """Scratch bytes for one kernel call (torch's caching allocator; stream-ordered reuse)."""
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if _POISON_WS[0] and ws.numel():
+        ws.fill_(0xFF)          # 0xFFFFFFFF = NaN as float32; 0xFFFF = NaN as bfloat16
+    return ws
 
 
 def stats_buffer_numel(C):
@@ -342,7 +363,7 @@ def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None):
     else:
         need = ctypes.c_size_t()
         check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
-        ws = torch.empty(need.value, dtype=torch.uint8, device=x.device) if need.value else None
+        ws = _workspace(need.value, x.device) if need.value else None
         check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
                                    ptr(stats), stats.numel() * 4 if stats is not None else 0, ptr(ws), need.value, stream()),
               "conv_forward")
@@ -414,7 +435,7 @@ class _Conv(torch.autograd.Function):
             nsplit = ctypes.c_int32()
             nbytes = ctypes.c_size_t()
             check(lib.vfd_wgrad_workspace(ctypes.byref(desc), ctypes.byref(nsplit), ctypes.byref(nbytes)), "wgrad_workspace")
-            ws = torch.empty(nbytes.value, dtype=torch.uint8, device=x.device)
+            ws = _workspace(nbytes.value, x.device)
             timer = _TIMER[0]
             if timer is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -434,7 +455,7 @@ class _Conv(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             bias = ctx.bias_param
             direct = _direct_grad(bias)
-            bws = torch.empty(lib.vfd_bias_grad_workspace(Cout), dtype=torch.uint8, device=x.device)
+            bws = _workspace(lib.vfd_bias_grad_workspace(Cout), x.device)
             if direct is not None:
                 check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), direct.data_ptr(), rows_out, Cout, 1.0, bws.data_ptr(),
                                         stream()), "bias_grad")
@@ -497,7 +518,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.vfd_bn_stats_from_sums(sums.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
                                              ptr(running_mean), ptr(running_var), ptr(nbt), stream()), "bn_stats_from_sums")
         else:
-            ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
+            ws = _workspace(lib.vfd_bn_workspace(rows, C), dev)
             check(lib.vfd_bn_stats(dtc, x.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
                                    ptr(running_mean), ptr(running_var), ptr(nbt), ws.data_ptr(), stream()), "bn_stats")
         y = torch.empty_like(x)
@@ -518,7 +539,7 @@ class _BnAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
+        ws = _workspace(lib.vfd_bn_workspace(rows, C), dev)
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
         db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
@@ -748,7 +769,7 @@ class _Loss(torch.autograd.Function):
             b = b.contiguous()
         rows = a.numel() // a.shape[-1]
         loss = torch.empty((), dtype=torch.float32, device=a.device)
-        ws = torch.empty(lib.vfd_loss_workspace(rows, C), dtype=torch.uint8, device=a.device)
+        ws = _workspace(lib.vfd_loss_workspace(rows, C), a.device)
         check(lib.vfd_loss_forward(kind, dtype_code(a.dtype), a.data_ptr(), ptr(b), bconst, loss.data_ptr(), rows, C,
                                    pos_weight, ws.data_ptr(), stream()), "loss_forward")
         ctx.meta = (kind, C, rows, bconst, pos_weight)
