@@ -71,7 +71,7 @@ def test_anogan_step_small(dt, dev, tmp_path):
         got = model.errors()
         for k, v in ref.items():
             g = got["%s/%s/train" % (k[4], k)]
-            assert abs(g - v) <= (2e-4 if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
         # step 0 compares the same weights; later steps also carry Adam's sign-amplified rounding noise of the
         # previous update (every weight moves ~lr whatever its gradient's size), hence the RMS metric there
         if f32 and it == 0:
@@ -114,7 +114,7 @@ def test_anogan_reference_geometry_golden(dev, tmp_path):
     model.z = z.to(dev)
     model.optimize_params()
     got = model.errors()
-    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 5e-4)
+    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 1e-4)
     check_summary(model.gen_fake.to_torch(), R["step_p0"]["fake"], 1e-3, "fake")
     for k, ref in R["after1"]["d"].items():
         if "running" in k:
@@ -149,7 +149,7 @@ def test_mygan_step_small(dt, dev, tmp_path):
         got = model.errors()
         for k, v in ref.items():
             g = got["%s/%s/train" % (k[4], k)]
-            assert abs(g - v) <= (2e-4 if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
         if f32 and it == 0:
             assert relerr(model.predict.to_torch(), pred_ref) < 5e-4, it
         else:
@@ -192,7 +192,7 @@ def test_mygan_reference_geometry_golden(dev, tmp_path):
     model.set_input((inp, inp, gt, torch.ones(2, 16)), gt_flow=gf, pre_flow=pf)
     model.optimize_params()
     got = model.errors()
-    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 5e-4)
+    check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["step_p0"]["errs"]}, R["step_p0"]["errs"], 1e-4)
     check_summary(model.predict.to_torch(), R["step_p0"]["predict"], 1e-3, "predict")
 
 
@@ -218,3 +218,45 @@ def test_ganomaly_golden(dev, tmp_path):
         got = model.errors()
         check_errs({k: got["%s/%s/train" % (k[4], k)] for k in R["steps"][it]["errs"]}, R["steps"][it]["errs"], 2e-4, "step %d" % it)
         check_summary(model.fake.to_torch(), R["steps"][it]["fake"], 1e-3, "fake %d" % it)
+
+
+def test_anogan_generalised_112(dev, tmp_path):
+    """BASELINE configs[2] geometry: anogan at 16x112x112 (seed volume (512,2,14,14), Linear(256*2*14*14, 1)), B=2.
+    The reference's NetD does not exist at 112 (fixture anogan.netd112_raises), so the check is HIP vs the oracle's
+    generalisation, which reduces to the reference modules at 128 (test_anogan_reference_geometry_golden): ONE oracle
+    step, compared with the float32 path (losses 1e-4 relative: north_star's tolerance) and with the bf16 path as
+    benchmarked (5e-2) on the same weights, noise and clips."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import anogan as HA
+    from vfd_oracle import anogan as OA
+    from vfd_oracle.weights import fill_module, seeded_normal, seeded_tensor
+    assert JS["anogan"]["netd112_raises"]
+    B, T, S = 2, 16, 112
+    og, od = fill_module(OA.NetG(T, S), 71).train(), fill_module(OA.NetD(T, S), 72).train()
+    _p0(og)
+    sd_g, sd_d = {k: v.clone() for k, v in og.state_dict().items()}, {k: v.clone() for k, v in od.state_dict().items()}
+    z, real = seeded_normal((B, 100), 73), seeded_tensor((B, 3, T, S, S), 74)
+    g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
+    ref, fake_ref = OA.step(og, od, g_opt, d_opt, real, z)
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 5e-2)):
+        F.set_compute_dtype(dt)
+        model = HA.AnoGAN(_args(tmp_path, "anogan", B, T, S), None)
+        assert model.netg.seed_shape == (512, 2, 14, 14) and model.netd.fc[0].in_features == 256 * 2 * 14 * 14
+        model.netg.load_state_dict(sd_g)
+        model.netd.load_state_dict(sd_d)
+        _p0(model.netg)
+        F.invalidate_weight_cache()
+        model.set_input((real, real, real[:, :1], torch.ones(B, T)))
+        model.z = z.to(dev)
+        model.optimize_params()
+        got = model.errors()
+        for k, v in ref.items():
+            g = got["%s/%s/train" % (k[4], k)]
+            assert abs(g - v) <= tol * max(abs(v), 1e-3), (dt, k, g, v)
+        if dt == torch.float32:
+            assert relerr(model.gen_fake.to_torch(), fake_ref) < 5e-4
+        else:
+            assert relrms(model.gen_fake.to_torch(), fake_ref) < 4e-2
+        del model
+        torch.cuda.empty_cache()
+    F.set_compute_dtype(torch.bfloat16)

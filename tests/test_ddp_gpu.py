@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(mode, world, tmp_path):
-    out = str(tmp_path / ("%s_%d.json" % (mode, world)))
+def _run(mode, world, tmp_path, which="ganomaly"):
+    out = str(tmp_path / ("%s_%s_%d.json" % (which, mode, world)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), mode, out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), mode, out, which], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=600)
@@ -29,9 +29,13 @@ def _run(mode, world, tmp_path):
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_two_ranks_match_single_process(mode, dev, tmp_path):
-    one = _run(mode, 1, tmp_path)
-    two = _run(mode, 2, tmp_path)
+@pytest.mark.parametrize("which", ["ganomaly", "anogan", "mygan"])
+def test_two_ranks_match_single_process(which, mode, dev, tmp_path):
+    """All three models: ganomaly / mygan (one backward per net and step), anogan (TWO backward passes into netD before
+    its reduction: GradReducer.arm(passes=2)); graph mode runs the models' step_program() with asynchronous
+    reductions between the captured graphs."""
+    one = _run(mode, 1, tmp_path, which)
+    two = _run(mode, 2, tmp_path, which)
     assert two["world"] == 2
     for k, v in one["errors"].items():
         assert abs(two["errors"][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, two["errors"][k], v)

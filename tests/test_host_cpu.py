@@ -173,6 +173,34 @@ for it in range(2):
     ref2(torch.tanh(ref1(xs + it))).pow(2).mean().backward()
     for p, r in zip(params, list(ref1.parameters()) + list(ref2.parameters())):
         assert torch.allclose(p.grad / world, r.grad, rtol=1e-5, atol=1e-7), (rank, it)
+# TWO backward passes into the same gradients before the optimiser step (AnoGAN's discriminator, reference
+# models/anogan.py:233-241): armed for two passes, no bucket may be reduced after the first, and the reduced
+# result is the rank-sum of BOTH passes
+launches = []
+orig_launch = red._launch
+red._launch = lambda b: (launches.append(b), orig_launch(b))[1]
+arena.zero_(); red.arm(passes=2)
+xa, xb = xs[rank * 2:(rank + 1) * 2], xs[rank * 2:(rank + 1) * 2] * 0.5 - 1.0
+lin2(torch.tanh(lin1(xa))).pow(2).mean().backward()
+assert launches == [], "a bucket was reduced after the first of two backward passes"
+lin2(torch.tanh(lin1(xb))).pow(2).mean().backward()
+assert sorted(launches) == list(range(len(red.buckets))), launches
+red.finish()
+ref1, ref2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)
+ref1.load_state_dict(lin1.state_dict()); ref2.load_state_dict(lin2.state_dict())
+(ref2(torch.tanh(ref1(xs))).pow(2).mean() + ref2(torch.tanh(ref1(xs * 0.5 - 1.0))).pow(2).mean()).backward()
+for p, r in zip(params, list(ref1.parameters()) + list(ref2.parameters())):
+    assert torch.allclose(p.grad / world, r.grad, rtol=1e-5, atol=1e-7), rank
+red._launch = orig_launch
+# graph-mode form: no hooks fire (suspended), every bucket is issued by reduce_async() and joined later
+arena.zero_(); red.reset(); red.suspended = True
+lin2(torch.tanh(lin1(xa))).pow(2).mean().backward()
+red.suspended = False
+red.reduce_async(); red.join()
+ref1.zero_grad(); ref2.zero_grad()
+ref2(torch.tanh(ref1(xs))).pow(2).mean().backward()
+for p, r in zip(params, list(ref1.parameters()) + list(ref2.parameters())):
+    assert torch.allclose(p.grad / world, r.grad, rtol=1e-5, atol=1e-7), rank
 # a frozen parameter must not stall the bucket logic
 params[0].requires_grad_(False); red.reset(); arena.zero_()
 lin2(torch.tanh(lin1(xs[rank * 2:(rank + 1) * 2]))).sum().backward(); red.finish()

@@ -97,6 +97,7 @@ class GradReducer:
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.passes = 1
         self.enabled = True      # toggled by the step (a frozen net's gradients are not reduced)
         self.suspended = False   # set while a hipGraph capture is open: no collective may be issued then
         self._hooks = []
@@ -112,11 +113,19 @@ class GradReducer:
         opt.grad_scale = 1.0 / r.world
         return r
 
-    def reset(self):
+    def arm(self, passes=1):
+        """Re-arm for the next optimiser step.  `passes` = number of backward passes that deposit gradients into this
+        net before finish() (AnoGAN's discriminator: two, reference models/anogan.py:233-241): a bucket's all-reduce
+        is launched when its LAST parameter has received its LAST contribution, i.e. after `passes` hook firings per
+        parameter, so the sum of all passes is reduced and no later backward writes into a bucket RCCL is reading."""
+        self.passes = passes
         for b, (_, _, idxs) in enumerate(self.buckets):
-            self.pending[b] = sum(1 for i in idxs if self.params[i].requires_grad)
+            self.pending[b] = passes * sum(1 for i in idxs if self.params[i].requires_grad)
             self.launched[b] = False
         self.handles = []
+
+    def reset(self):
+        self.arm(1)
 
     def _launch(self, b):
         if self.launched[b]:
@@ -136,19 +145,28 @@ class GradReducer:
                 self._launch(b)
         return hook
 
-    def reduce_all(self):
-        """All buckets now, on the current stream (used between captured graph phases, where the backward that
-        produced the gradients is a graph replay and no autograd hook fires)."""
-        if self.world > 1:
-            for lo, hi, _ in self.buckets:
-                tdist.all_reduce(self.arena[lo:hi], op=tdist.ReduceOp.SUM)
+    def reduce_async(self):
+        """Issue every bucket's all-reduce now, asynchronously (graph mode: the backward that produced the gradients is a
+        graph replay, no autograd hook fires).  RCCL's stream waits for the work already queued on the current stream
+        and the current stream does NOT wait for RCCL: whatever is launched next (the other net's backward graph) runs
+        beside the collective.  join() makes the current stream wait."""
+        for b in range(len(self.buckets)):
+            self.launched[b] = False
+            self._launch(b)
+
+    def join(self):
+        for h in self.handles:
+            h.wait()
         self.reset()
+
+    def reduce_all(self):
+        """All buckets now, and wait (blocking form of reduce_async + join)."""
+        self.reduce_async()
+        self.join()
 
     def finish(self):
         """Launch whatever has not been launched (parameters that received no gradient), wait for all buckets
         (the current stream waits; the host does not block with RCCL), and re-arm for the next backward."""
         for b in range(len(self.buckets)):
             self._launch(b)
-        for h in self.handles:
-            h.wait()
-        self.reset()
+        self.join()

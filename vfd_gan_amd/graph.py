@@ -15,14 +15,15 @@ from . import functional as F
 
 class GraphedStep:
     """Captured training step.  world_size == 1: one graph for the whole step.  Data parallel: the model's
-    ``step_phases()`` are captured as separate graphs and the RCCL gradient reductions run between them on the same
-    stream (collectives are never captured)."""
+    ``step_program()`` — a list of ("graph", fn) / ("reduce", reducer) / ("join", reducer) — is executed per step:
+    every "graph" entry is captured once into its own hipGraph and replayed; collectives are never captured, they are
+    issued between the graphs (asynchronously: "reduce" returns at once, the next graph runs beside the collective,
+    "join" makes the stream wait for it)."""
 
     def __init__(self, model, warmup=2):
         self.model = model
         self.warmup = warmup
-        self.graphs = None
-        self.phases = None
+        self.program = None      # [(kind, fn / reducer, graph or None)]
 
     def _eager_step(self):
         m = self.model
@@ -36,6 +37,9 @@ class GraphedStep:
         Capturing only RECORDS the step (its kernels do not run): training state advances by `warmup` steps."""
         from . import dist as vdist
         if self.warmup < 1:
+            # capturing a backward pass whose leaf-gradient streams were never initialised off the default stream makes
+            # autograd insert a cross-stream wait on the (non-capturing) default stream: the capture is invalidated
+            # and hipStreamEndCapture faults instead of returning an error (round 1, gpurun_out/t7.log)
             raise ValueError("at least one warm-up step on the side stream is required before capture")
         if F._TIMER[0] is not None:
             raise RuntimeError("kernel timing events cannot be recorded inside a graph capture")
@@ -48,29 +52,36 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if vdist.world_size() > 1:
-            if not hasattr(m, "step_phases"):
-                raise NotImplementedError("%s has no step_phases() for data-parallel graph capture" % type(m).__name__)
-            self.phases = m.step_phases()
+            if not hasattr(m, "step_program"):
+                raise NotImplementedError("%s has no step_program() for data-parallel graph capture" % type(m).__name__)
+            program = m.step_program()
         else:
-            self.phases = [(self._eager_step, None)]
-        reducers = [r for _, r in self.phases if r is not None]
+            program = [("graph", self._eager_step)]
+        reducers = {id(r): r for kind, r in program if kind != "graph"}.values()
         for r in reducers:
             r.suspended = True         # no collective may be issued while a capture is open
-        self.graphs = []
+        self.program = []
         pool = None
         try:
-            for fn, _ in self.phases:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    fn()
-                pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool
-                self.graphs.append(g)
+            for kind, obj in program:
+                if kind == "graph":
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        obj()
+                    pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool
+                    self.program.append((kind, obj, g))
+                else:
+                    self.program.append((kind, obj, None))
         finally:
             for r in reducers:
                 r.suspended = False
                 r.reset()
         torch.cuda.synchronize()
         return self
+
+    @property
+    def graphs(self):
+        return [g for _, _, g in self.program if g is not None]
 
     def load_input(self, batch):
         """Copy a new (input, real, gt, lb) batch into the buffers the captured graph reads."""
@@ -84,10 +95,13 @@ class GraphedStep:
                 setattr(m, k, o)
 
     def replay(self):
-        for g, (_, red) in zip(self.graphs, self.phases):
-            g.replay()
-            if red is not None:
-                red.reduce_all()
+        for kind, obj, g in self.program:
+            if kind == "graph":
+                g.replay()
+            elif kind == "reduce":
+                obj.reduce_async()
+            else:
+                obj.join()
         m = self.model
         if hasattr(m, "d_collapsed") and m.d_collapsed():
             m.reinit_d()                   # reference models/ganomaly.py:519 (host decision, outside the graph)

@@ -126,41 +126,69 @@ class AnoGAN(GANBaseModel):
         super(AnoGAN, self).set_input(data)
         self.real_cl = F.to_cl(self.real)
 
-    def optimize_params(self):
+    # ---- the step, reference :229-250, in the three pieces data-parallel graph capture needs ------------------------
+    def _d_phase(self, join=True):
+        """NetD on real and on G(z).detach() (reference :231-241): TWO backward passes deposit into netD's gradients,
+        so its reducer is armed for two (a bucket is reduced once both passes have written it)."""
         F.dropout_begin_step(self.device)
-        # NetD  (reference :231-243)
         self.d_opt.zero_grad()
+        self.reducer_d.arm(passes=2)
         dis_real = self.netd(self.real_cl)[0]
-        dis_loss_real = self.loss(dis_real, self.ones_label)
-        dis_loss_real.backward()
+        self.dis_loss_real = self.loss(dis_real, self.ones_label)
+        self.dis_loss_real.backward()
 
         # torch's default device generator is graph-safe (its Philox offset advances under hipGraph replay)
         z = self.z if self.z is not None else torch.randn(self.args.batchsize, 100, device=self.device)
-        gen_fake = self.netg(F.to_cl(z))
-        dis_fake = self.netd(gen_fake.detach())[0]
-        dis_loss_fake = self.loss(dis_fake, self.zeros_label)
-        dis_loss_fake.backward()
-        dis_loss = dis_loss_real + dis_loss_fake
-        self.reducer_d.finish()
-        self.d_opt.step()
+        self.gen_fake_t = self.netg(F.to_cl(z))
+        dis_fake = self.netd(self.gen_fake_t.detach())[0]
+        self.dis_loss_fake = self.loss(dis_fake, self.zeros_label)
+        self.dis_loss_fake.backward()
+        self.dis_loss = self.dis_loss_real + self.dis_loss_fake
+        if join:
+            self.reducer_d.finish()
 
-        # NetG  (reference :246-250).  netD's own gradients from this backward are never used by the reference
-        # (the next step starts with netd.zero_grad()), so netD is frozen here and only the data gradient flows.
+    def _g_phase(self, join=True):
+        """NetG (reference :246-250).  netD's own gradients from this backward are never used by the reference
+        (the next step starts with netd.zero_grad()), so netD is frozen here and only the data gradient flows."""
         self.g_opt.zero_grad()
         for p in self.netd.parameters():
             p.requires_grad_(False)
         self.reducer_d.enabled = False
         try:
-            dis_fake = self.netd(gen_fake)[0]
-            gen_loss = self.loss(dis_fake, self.ones_label)
-            gen_loss.backward()
+            dis_fake = self.netd(self.gen_fake_t)[0]
+            self.gen_loss = self.loss(dis_fake, self.ones_label)
+            self.gen_loss.backward()
         finally:
             for p in self.netd.parameters():
                 p.requires_grad_(True)
             self.reducer_d.enabled = True
-        self.reducer_g.finish()
-        self.g_opt.step()
+        if join:
+            self.reducer_g.finish()
 
-        self.gen_fake = gen_fake.detach()
-        self.errors_dict.update({'d/err_d/train': dis_loss, 'g/err_g/train': gen_loss,
-                                 'd/err_d_real/train': dis_loss_real, 'd/err_d_fake/train': dis_loss_fake})
+    def _publish(self):
+        self.gen_fake = self.gen_fake_t.detach()
+        self.errors_dict.update({'d/err_d/train': self.dis_loss, 'g/err_g/train': self.gen_loss,
+                                 'd/err_d_real/train': self.dis_loss_real, 'd/err_d_fake/train': self.dis_loss_fake})
+
+    def optimize_params(self):
+        self._d_phase()
+        self.d_opt.step()
+        self._g_phase()
+        self.g_opt.step()
+        self._publish()
+
+    def step_program(self):
+        """Graph capture under data parallelism (vfd_gan_amd.graph.GraphedStep).  The generator phase reads the
+        UPDATED discriminator, so netD's reduction cannot be deferred; netG's is joined right before its Adam update."""
+        def a():
+            self._d_phase(join=False)
+
+        def b():
+            self.d_opt.step()
+            self._g_phase(join=False)
+
+        def c():
+            self.g_opt.step()
+            self._publish()
+        return [("graph", a), ("reduce", self.reducer_d), ("join", self.reducer_d), ("graph", b),
+                ("reduce", self.reducer_g), ("join", self.reducer_g), ("graph", c)]

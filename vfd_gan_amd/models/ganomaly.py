@@ -272,9 +272,12 @@ class Ganomaly(GANBaseModel):
             e = e / self.world_size
         return e.item() < 1e-5
 
-    def step_phases(self):
-        """The step as three collective-free phases and the gradient reductions between them, for hipGraph capture
-        under data parallelism (vfd_gan_amd.graph.GraphedStep): [(phase, reducer to run after it or None), ...]."""
+    def step_program(self):
+        """The step for hipGraph capture under data parallelism (vfd_gan_amd.graph.GraphedStep): collective-free graphs
+        with the gradient reductions issued between them.  optimizer_g.step() is moved behind backward_d — backward_d
+        reads netD's weights and the activations forward_d saved BEFORE the generator update in the reference order too
+        (models/ganomaly.py:502-519), so the result is identical — which lets netG's all-reduce run beside netD's
+        backward pass, and netD's beside netG's Adam update."""
         def a():
             self.forward_g()
             self.forward_d()
@@ -282,14 +285,17 @@ class Ganomaly(GANBaseModel):
             self.backward_g(join=False)
 
         def b():
-            self.optimizer_g.step()
             self.optimizer_d.zero_grad()
             self.backward_d(join=False)
 
         def c():
+            self.optimizer_g.step()
+
+        def d():
             self.optimizer_d.step()
             self._publish_errors()
-        return [(a, self.reducer_g), (b, self.reducer_d), (c, None)]
+        return [("graph", a), ("reduce", self.reducer_g), ("graph", b), ("reduce", self.reducer_d),
+                ("join", self.reducer_g), ("graph", c), ("join", self.reducer_d), ("graph", d)]
 
     def _publish_errors(self):
         self.errors_dict.update({'g/err_g/train': self.err_g, 'g/err_g_adv/train': self.err_g_adv,

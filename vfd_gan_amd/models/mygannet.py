@@ -212,7 +212,7 @@ class MyGAN(GANBaseModel):
         self.s_pred_real, self.s_feat_real, self.t_pred_real, self.t_feat_real = self.netd(gt_3ch, self.gt_flow)
         self.s_pred_fake, self.s_feat_fake, self.t_pred_fake, self.t_feat_fake = self.netd(pre_3ch, self.pre_flow)
 
-    def backward_g(self):
+    def backward_g(self, join=True):
         # Everything netD sees is detached from netG (reference :279-286), so the adversarial term has no gradient
         # path to netG; its gradients w.r.t. netD are discarded by optimizer_d.zero_grad() (:364).  It is therefore
         # evaluated for its VALUE only, and only the reconstruction term is back-propagated.
@@ -222,11 +222,12 @@ class MyGAN(GANBaseModel):
         err_g_con = self.l_con(self.predict, self.gt_cl)
         err_g = err_g_adv * self.args.w_adv + err_g_con * self.args.w_con
         err_g.backward()
-        self.reducer_g.finish()
+        if join:
+            self.reducer_g.finish()
         self.errors_dict.update({'g/err_g/train': err_g, 'g/err_g_adv/train': err_g_adv, 'g/err_g_adv_s/train': err_g_adv_s,
                                  'g/err_g_adv_t/train': err_g_adv_t, 'g/err_g_con/train': err_g_con})
 
-    def backward_d(self):
+    def backward_d(self, join=True):
         err_d_real_s = self.l_bce(self.s_pred_real, self.real_label)
         err_d_real_t = self.l_bce(self.t_pred_real, self.real_label)
         err_d_fake_s = self.l_bce(self.s_pred_fake, self.gout_label)
@@ -238,11 +239,40 @@ class MyGAN(GANBaseModel):
                                  'd/err_d_fake_s/train': err_d_fake_s, 'd/err_d_fake_t/train': err_d_fake_t,
                                  'd/err_d_real/train': err_d_real, 'd/err_d_fake/train': err_d_fake, 'd/err_d/train': err_d})
         err_d.backward()
-        self.reducer_d.finish()
+        if join:
+            self.reducer_d.finish()
 
     def reinit_d(self):
+        """Reference :253-256.  The initialiser writes through `.data` (no version bump): the packed-filter cache is
+        invalidated explicitly, and under data parallelism rank 0's new weights are broadcast so replicas stay equal."""
         self.netd.apply(weights_init)
-        print('Reloading Net d')
+        vdist.broadcast_module(self.netd)
+        F.invalidate_weight_cache()
+        if self.rank == 0:
+            print('Reloading Net d')
+
+    def step_program(self):
+        """Graph capture under data parallelism (vfd_gan_amd.graph.GraphedStep): as Ganomaly.step_program — netG's Adam
+        update is moved behind netD's backward pass (which reads nothing of netG: everything netD saw was detached,
+        reference :279-286), so netG's all-reduce overlaps netD's backward and netD's overlaps netG's update."""
+        def a():
+            F.dropout_begin_step(self.device)
+            self.forward_g()
+            self.forward_d()
+            self.optimizer_g.zero_grad()
+            self.backward_g(join=False)
+
+        def b():
+            self.optimizer_d.zero_grad()
+            self.backward_d(join=False)
+
+        def c():
+            self.optimizer_g.step()
+
+        def d():
+            self.optimizer_d.step()
+        return [("graph", a), ("reduce", self.reducer_g), ("graph", b), ("reduce", self.reducer_d),
+                ("join", self.reducer_g), ("graph", c), ("join", self.reducer_d), ("graph", d)]
 
     def optimize_params(self):
         F.dropout_begin_step(self.device)
