@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: video clips/sec per GAN step on MI355X (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            [--model ganomaly|anogan|mygan]
     (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload): BASELINE.json configs[1] — ganomaly, 16x112x112 clips, bf16 MFMA storage with f32
+Default workload (config.workload): BASELINE.json configs[1] — ganomaly, 16x112x112 clips, bf16 MFMA storage with f32
 accumulation / f32 master weights, batch 32 clips per GPU (= 512 frames of 3x112x112 through the 2-D nets).
-One "step" = one full optimize_params(): G forward, 4 D forwards, backward_g, Adam(G), backward_d, Adam(D)
-(reference models/ganomaly.py:502-519).  Synthetic clips are generated on the host and are resident
-in HBM before the timed region.  Data parallel (weak scaling): every rank steps its own 32 clips, gradients are
-summed over RCCL inside the step.
+``--model anogan`` = configs[2] (3-D conv G/D step, 16x112x112, batch 32), ``--model mygan`` = configs[3]'s per-GPU
+workload ((2+1)D U-Net + spatial/temporal discriminators, 16x224x224, batch 8 clips per GPU).
+One "step" = one full optimize_params() of the model (reference models/ganomaly.py:502-519, models/anogan.py:229-250,
+models/mygannet.py:350-367).  Synthetic clips are generated on the host and are resident in HBM before
+the timed region.  Data parallel (weak scaling): every rank steps its own clips, gradients are summed over RCCL
+inside the step.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant
-MFMA kernel during the timed steps; `cpu_baseline` times the oracle (the CPU restatement of the reference step,
-stock torch.nn float32) on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` is the dominant MFMA kernel: algorithmic FLOPs / its average launch duration
+from HIP events on the launch stream, taken in an eager pass of the same step right after the timed graph replays
+(events cannot be recorded inside a replayed graph) with the stream kept GPU-bound (a device-side delay in front of
+every step lets the host run ahead, so an event pair brackets the kernel and not the host's launch gap);
+`cpu_baseline` times the oracle (the CPU restatement of the reference step, stock torch.nn float32) on this box's host
+cores on a bounded sample.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -30,38 +36,63 @@ import torch  # noqa: E402
 import torch.distributed as tdist  # noqa: E402
 
 MFMA_PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_PEAK_F32_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
-
-def ganomaly_step_flops(isize, frames, ngf=64, nz=100, nc=3):
-    """Algorithmic FLOPs (2*MAC of every conv / conv-transpose) of ONE ganomaly step on `frames` frames:
-    3*G + 12*D forward-equivalents (1 G fwd + 2 for its backward; 4 D fwd + 4 D backward passes of 2 each),
-    the reference's own accounting."""
-    def enc(nz_out):
-        f, c, s = 0.0, ngf, isize // 2
-        f += 2.0 * s * s * ngf * nc * 16
-        floor = isize // 2
-        while floor >= 8 and floor % 2 == 0:
-            floor //= 2
-        while s > floor:
-            s //= 2
-            f += 2.0 * s * s * (2 * c) * c * 16
-            c *= 2
-        f += 2.0 * nz_out * c * s * s
-        return f
-    g = 2 * enc(nz) + enc(nz)   # the decoder mirrors the encoder
-    d = enc(1)
-    return frames * (3 * g + 12 * d)
+# reference accounting of one step in forward-equivalents of the two nets: 1 fwd + 2 for a backward
+STEP_MULT = {"ganomaly": (3, 12), "anogan": (3, 9), "mygan": (3, 10)}
+DEFAULTS = {"ganomaly": dict(batch=32, isize=112, steps=100), "anogan": dict(batch=32, isize=112, steps=20),
+            "mygan": dict(batch=8, isize=224, steps=20)}
 
 
-def build_model(args_ns, dtype):
+def make_args(model, batch, nfr, isize, local):
+    d = dict(batchsize=batch, nfr=nfr, isize=isize, ich=3, freq=10 ** 9, ep=1, model=model,
+             result_root=tempfile.mkdtemp(prefix="vfd_bench_"), gpu=[local], ae=False, pos_weight=2)
+    d.update(dict(lr=2e-4, beta1=0.5, w_adv=1, w_con=50) if model == "ganomaly" else dict(lr=2e-5, beta1=0.5, w_adv=1, w_con=10))
+    return types.SimpleNamespace(**d)
+
+
+def build_model(model, args_ns, dtype):
     from vfd_gan_amd import functional as F
-    from vfd_gan_amd.models.ganomaly import Ganomaly
     F.set_compute_dtype(dtype)
     torch.manual_seed(1234)     # identical initial weights on every rank (and broadcast again inside)
-    import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the trainer base class announces its save path (reference behaviour):
-        return Ganomaly(args_ns, None)               # stdout carries the ONE JSON line only
+        if model == "ganomaly":                      # stdout carries the ONE JSON line only
+            from vfd_gan_amd.models.ganomaly import Ganomaly as M
+        elif model == "anogan":
+            from vfd_gan_amd.models.anogan import AnoGAN as M
+        else:
+            from vfd_gan_amd.models.mygannet import MyGAN as M
+        return M(args_ns, None)
+
+
+def forward_flops(model_name, m):
+    """Algorithmic FLOPs (2*MAC of every conv / conv-transpose / linear) of ONE forward of netG and of netD on the
+    resident batch, counted by the launch timer's per-launch FLOP figures (no restated layer table)."""
+    from vfd_gan_amd import functional as F
+    out = []
+    with torch.no_grad():
+        for which in ("g", "d"):
+            t = F.KernelTimer()
+            F.set_kernel_timer(t)
+            try:
+                if model_name == "ganomaly":
+                    m.netg(m.x) if which == "g" else m.netd(m.x)
+                elif model_name == "anogan":
+                    if which == "g":
+                        m.netg(F.to_cl(torch.randn(m.args.batchsize, 100, device=m.device)))
+                    else:
+                        m.netd(m.real_cl)
+                else:
+                    if which == "g":
+                        m.netg(m.input_cl)
+                    else:
+                        m.netd(F.gray2rgb(m.gt_cl), m.gt_flow)
+            finally:
+                F.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            out.append(sum(r[1] for r in t.records))
+    return out
 
 
 def host_cores():
@@ -78,35 +109,54 @@ def host_cores():
     return min(n, int(os.environ.get("VFD_CPU_BASELINE_CORES", "16")))
 
 
-def cpu_baseline(isize, nfr, steps=3, clips=16):
-    """The oracle step on the host cores, bounded sample (~10-20 s): `clips` clips, 1 warm-up + `steps` timed steps."""
+def cpu_baseline(model, isize, nfr):
+    """The oracle step on the host cores, bounded sample (~10-30 s): 1 warm-up + a few timed steps on a few clips."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from vfd_oracle import ganomaly as OG
-    from vfd_gan_amd.lib.data import synthetic_batch
+    from vfd_gan_amd.lib.data import synthetic_batch, synthetic_flow
     cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
-    opt = OG.make_opt(isize=isize)
-    og, od = OG.NetG(opt), OG.NetD(opt)
-    opt_g, opt_d = OG.make_optimizers(og, od, opt)
-    x = OG.fold_frames(synthetic_batch(clips, nfr, isize, 3, seed=1234)[0])
-    OG.step(og, od, opt_g, opt_d, x, opt)
+    if model == "ganomaly":
+        from vfd_oracle import ganomaly as OG
+        clips, steps = 16, 3
+        opt = OG.make_opt(isize=isize)
+        og, od = OG.NetG(opt), OG.NetD(opt)
+        opt_g, opt_d = OG.make_optimizers(og, od, opt)
+        x = OG.fold_frames(synthetic_batch(clips, nfr, isize, 3, seed=1234)[0])
+        run = lambda: OG.step(og, od, opt_g, opt_d, x, opt)    # noqa: E731
+    elif model == "anogan":
+        from vfd_oracle import anogan as OA
+        clips, steps = 2, 2
+        og, od = OA.NetG(nfr, isize).train(), OA.NetD(nfr, isize).train()
+        g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
+        real, z = synthetic_batch(clips, nfr, isize, 3, seed=1234)[1], torch.randn(clips, 100)
+        run = lambda: OA.step(og, od, g_opt, d_opt, real, z)   # noqa: E731
+    else:
+        from vfd_oracle import mygannet as OM
+        clips, steps = 2, 2
+        og, od = OM.NetG().train(), OM.NetD(OM.make_args(nfr, isize)).train()
+        opt_g, opt_d = OM.make_optimizers(og, od)
+        inp, _, gt, _ = synthetic_batch(clips, nfr, isize, 3, seed=1234)
+        gf, pf = synthetic_flow(clips, nfr, isize, 1), synthetic_flow(clips, nfr, isize, 2)
+        run = lambda: OM.step(og, od, opt_g, opt_d, inp, gt, gf, pf)    # noqa: E731
+    run()
     t0 = time.perf_counter()
     for _ in range(steps):
-        OG.step(og, od, opt_g, opt_d, x, opt)
+        run()
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle ganomaly step (stock torch.nn f32 on the host cores), %d clips = %d frames %dx%d, 1 warm-up + %d "
-                      "timed steps (%.2f s/step)" % (clips, clips * nfr, isize, isize, steps, dt)}
+            "sample": "oracle %s step (stock torch.nn f32 on the host cores), %d clips of %dx%dx%d, 1 warm-up + %d "
+                      "timed steps (%.2f s/step)" % (model, clips, nfr, isize, isize, steps, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--model", default="ganomaly", choices=["ganomaly", "anogan", "mygan"])
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
-    ap.add_argument("--isize", type=int, default=112)
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
+    ap.add_argument("--isize", type=int, default=None)
     ap.add_argument("--nfr", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,6 +164,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying a hipGraph")
     ap.add_argument("--layers", action="store_true", help="print a per-geometry table of the MFMA kernels to stderr")
     a = ap.parse_args()
+    for k, v in DEFAULTS[a.model].items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
 
     from vfd_gan_amd import dist as vdist
     from vfd_gan_amd import functional as F
@@ -128,12 +181,19 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 
-    ns = types.SimpleNamespace(batchsize=a.batch, nfr=a.nfr, isize=a.isize, ich=3, lr=2e-4, beta1=0.5, w_adv=1, w_con=50,
-                               freq=10 ** 9, ep=1, model="ganomaly", result_root=tempfile.mkdtemp(prefix="vfd_bench_"), gpu=[local])
-    model = build_model(ns, dtype)
+    model = build_model(a.model, make_args(a.model, a.batch, a.nfr, a.isize, local), dtype)
     batch = synthetic_batch(a.batch, a.nfr, a.isize, 3, seed=1234 + rank)
     model.set_input(batch)          # clips resident in HBM (layout conversion to channels-last bf16 included)
     torch.cuda.synchronize()
+    g_fwd, d_fwd = forward_flops(a.model, model)
+    mg, md = STEP_MULT[a.model]
+    step_flops_ref = mg * g_fwd + md * d_fwd
+
+    def eager_step():
+        if a.model == "ganomaly":
+            model.optimize_params(check_collapse=False)
+        else:
+            model.optimize_params()
 
     def barrier():
         vdist.barrier()
@@ -156,82 +216,107 @@ def main():
             tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
             ok = int(flag.item())
         use_graph = bool(ok)
-    if use_graph:
-        run = step.replay
-        for _ in range(a.warmup):
-            run()
-    else:
-        run = model.optimize_params
-        for _ in range(a.warmup):
-            run()
-        if not a.no_kernel_timer:
-            timer = F.KernelTimer()
-            F.set_kernel_timer(timer)
+    run = step.replay if use_graph else eager_step
+    for _ in range(a.warmup):
+        run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
     barrier()
     elapsed = time.perf_counter() - t0
-    F.set_kernel_timer(None)
-    timer_steps = a.steps
-    if use_graph and not a.no_kernel_timer:
-        # HIP events cannot be recorded inside a replayed graph: the per-kernel roofline is taken from an eager pass
-        # of the SAME step (same kernels, same launches) right after the timed region
-        timer_steps = min(a.steps, 5)
-        timer = F.KernelTimer()
-        F.set_kernel_timer(timer)
-        for _ in range(timer_steps):
-            model.optimize_params()
-        torch.cuda.synchronize()
-        F.set_kernel_timer(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms = elapsed / a.steps * 1e3
+
+    timer_steps = 0
+    if not a.no_kernel_timer:      # every rank takes part (the eager step issues the gradient collectives)
+        # per-kernel pass, after the timed region: eager launches of the SAME step with HIP events around every MFMA
+        # kernel.  Eager mode is host-bound (Python issues a launch every ~5 us), so a device-side delay of about one
+        # eager step's host time goes in front of each step: the host runs ahead, the launches queue up behind the
+        # delay and then execute back to back, and an event pair measures the kernel, not the launch gap.
+        timer_steps = 3
+        eager_step()
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        eager_step()
+        host_s = time.perf_counter() - h0       # host time of one eager step (launch-bound)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(20_000_000)           # calibrate the delay kernel's tick on this device
+        e1.record()
+        torch.cuda.synchronize()
+        ticks_per_s = 20_000_000 / max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+        cyc = int(max(host_s, ms * 1e-3) * 1.3 * ticks_per_s)
+        timer = F.KernelTimer()
+        for _ in range(timer_steps):
+            torch.cuda._sleep(cyc)
+            F.set_kernel_timer(timer)
+            eager_step()
+            F.set_kernel_timer(None)
+            torch.cuda.synchronize()
+    if world > 1:
+        vdist.barrier()
 
     if rank == 0:
-        ms = elapsed / a.steps * 1e3
         clips_s = world * a.batch * a.steps / elapsed
-        step_flops = ganomaly_step_flops(a.isize, a.batch * a.nfr)
+        peak = MFMA_PEAK_BF16_TFLOPS if a.dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+        names = {"ganomaly": "ganomaly 16x%d x%d %s batch=%d clips/GPU (BASELINE.json configs[1]): frames folded to (%d,3,%d,%d), "
+                             "generalised pyramid 112-56-28-14-7, nz=100 ngf=64, full optimize_params (G fwd, 4 D fwd, backward_g, "
+                             "Adam, backward_d, Adam)" % (a.isize, a.isize, a.dtype, a.batch, a.batch * a.nfr, a.isize, a.isize),
+                 "anogan": "anogan 16x%dx%d %s batch=%d clips/GPU (BASELINE.json configs[2]): 3-D conv NetG (seed volume 512x2x%dx%d) / "
+                           "NetD, full optimize_params (D on real, G fwd, D on fake, Adam(D), D on G(z), Adam(G))"
+                           % (a.isize, a.isize, a.dtype, a.batch, a.isize // 8, a.isize // 8),
+                 "mygan": "mygan 16x%dx%d %s batch=%d clips/GPU (BASELINE.json configs[3], per-GPU workload): (2+1)D U-Net NetG + "
+                          "spatial/temporal NetD, full optimize_params; flow streams are synthetic inputs of the step"
+                          % (a.isize, a.isize, a.dtype, a.batch)}
         out = {
-            "metric": "video clips/sec (Nx3x16x112x112) per GAN step", "value": round(clips_s, 3), "unit": "clips/s",
+            "metric": "video clips/sec (Nx3x16x%dx%d) per GAN step" % (a.isize, a.isize), "value": round(clips_s, 3), "unit": "clips/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "ganomaly 16x112x112 %s batch=%d clips/GPU (BASELINE.json configs[1]): frames folded "
-                                   "to (%d,3,%d,%d), generalised pyramid 112-56-28-14-7, nz=100 ngf=64, full "
-                                   "optimize_params (G fwd, 4 D fwd, backward_g, Adam, backward_d, Adam)"
-                                   % (a.dtype, a.batch, a.batch * a.nfr, a.isize, a.isize),
-                       "global_batch": world * a.batch, "frames_per_clip": a.nfr, "parallelism": "dp%d" % world,
+            "config": {"workload": names[a.model], "global_batch": world * a.batch, "frames_per_clip": a.nfr,
+                       "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay of the captured step" if use_graph else "eager (one Python launch per kernel)"},
-            "step_algorithmic_tflop": round(step_flops / 1e12, 3),
-            "step_mfma_frac": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_BF16_TFLOPS, 4),
+            # the reference's accounting: every forward and backward pass of both nets, including the netD gradient work of
+            # the generator update that the reference computes and then discards (this build skips it: DESIGN.md 2.3)
+            "step_reference_tflop": round(step_flops_ref / 1e12, 3),
+            "step_reference_mfma_frac": round(step_flops_ref / (ms * 1e-3) / 1e12 / peak, 4),
             "losses": {k: round(v, 6) for k, v in model.errors().items()},
         }
-        if timer is not None and a.layers:
-            for (name, geom), d in sorted(timer.by_geometry().items(), key=lambda kv: -kv[1]["ms"]):
-                print("%-34s %-62s x%-3d %8.1f us/launch %7.1f TF/s" % (name, geom, d["launches"] // timer_steps,
-                      d["ms"] * 1e3 / d["launches"], d["flops"] / max(d["ms"], 1e-9) / 1e9), file=sys.stderr)
         if timer is not None:
             summ = timer.summary()
-            dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            name, d = dom
+            executed = sum(v["flops"] for v in summ.values()) / timer_steps
+            mfma_ms = sum(v["ms"] for v in summ.values()) / timer_steps
+            # what the MFMA kernels actually execute per step (sum of the per-launch algorithmic FLOPs of every launch)
+            out["step_executed_tflop"] = round(executed / 1e12, 3)
+            out["step_mfma_frac"] = round(executed / (ms * 1e-3) / 1e12 / peak, 4)
+            out["mfma_kernels_ms_per_step"] = round(mfma_ms, 3)
+            if a.layers:
+                for (name, geom), d in sorted(timer.by_geometry().items(), key=lambda kv: -kv[1]["ms"]):
+                    print("%-34s %-66s x%-3d %8.1f us/launch %7.1f TF/s" % (name, geom, d["launches"] // timer_steps,
+                          d["ms"] * 1e3 / d["launches"], d["flops"] / max(d["ms"], 1e-9) / 1e9), file=sys.stderr)
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            peak = MFMA_PEAK_BF16_TFLOPS if a.dtype == "bf16" else 157.3
             traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")   # runs folded by tools/pmc_traffic.py)
-            if a.dtype == "bf16" and os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            for tname in ("r02_traffic_%s.json" % a.model, "r01_traffic.json"):        # runs folded by tools/pmc_traffic.py)
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if a.dtype == "bf16" and os.path.exists(tpath):
+                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+                    if traffic is not None or tname.startswith("r02"):
+                        break
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": traffic,
                                "launches_per_step": d["launches"] // timer_steps,
-                               "timed_in": ("eager pass after the timed region" if use_graph else "timed region"),
+                               "timed_in": "eager pass after the timed region, stream kept GPU-bound by a device-side delay",
                                "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches_per_step": v["launches"] // timer_steps, "ms_per_step": round(v["ms"] / timer_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in sorted(summ.items())}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.isize, a.nfr)
+            out["cpu_baseline"] = cpu_baseline(a.model, a.isize, a.nfr)
         print(json.dumps(out), flush=True)
     if world > 1:
         vdist.barrier()

@@ -731,6 +731,19 @@ def dropout_begin_step(device):
     st["calls"] = 0
 
 
+def dropout_state():
+    """(seed, device step counter) for checkpoints: with it a resumed run draws the masks the original would have."""
+    st = _DROPOUT_STATE
+    return {"seed": int(st["seed"]), "step": int(st["step_dev"].item()) if st["step_dev"] is not None else 0}
+
+
+def set_dropout_state(state, device):
+    st = _DROPOUT_STATE
+    st["seed"] = int(state["seed"])
+    st["step_dev"] = torch.full((1,), int(state["step"]), dtype=torch.int64, device=device)
+    st["calls"] = 0
+
+
 def set_dropout_mask_provider(fn):
     """Parity hook: fn(logical_shape, p, call_index) -> bool/uint8 keep-mask (torch tensor, reference layout
     (N,C,D,H,W)) or None.  Lets tests impose the masks the CPU oracle used (torch's CPU and device RNG streams

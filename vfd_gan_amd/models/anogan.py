@@ -121,6 +121,9 @@ class AnoGAN(GANBaseModel):
         self.ones_label, self.zeros_label = 1.0, 0.0
         torch.cuda.manual_seed(4321 + 7919 * self.rank)     # per-rank noise streams
         self.z = None                                       # tests may impose the noise
+        if self.load_pretrained():           # --resume (reference :133-143); last, so that a checkpointed RNG state survives
+            vdist.broadcast_module(self.netg)
+            vdist.broadcast_module(self.netd)
 
     def set_input(self, data):
         super(AnoGAN, self).set_input(data)

@@ -211,6 +211,9 @@ class Ganomaly(GANBaseModel):
         self.optimizer_g = hoptim.Adam(self.netg.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
         self.reducer_g = vdist.GradReducer.for_optimizer(self.optimizer_g)
         self.reducer_d = vdist.GradReducer.for_optimizer(self.optimizer_d)
+        if self.load_pretrained():           # --resume (reference: right after weights_init)
+            vdist.broadcast_module(self.netg)
+            vdist.broadcast_module(self.netd)
 
     # ---- reference-named phases ------------------------------------------------------------------------------
     def set_input(self, data):

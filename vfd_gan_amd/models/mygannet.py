@@ -191,6 +191,9 @@ class MyGAN(GANBaseModel):
         self.optimizer_g = hoptim.Adam(self.netg.parameters(), lr=self.args.lr, betas=(self.args.beta1, 0.999))
         self.reducer_g = vdist.GradReducer.for_optimizer(self.optimizer_g)
         self.reducer_d = vdist.GradReducer.for_optimizer(self.optimizer_d)
+        if self.load_pretrained():           # --resume (reference: right after weights_init)
+            vdist.broadcast_module(self.netg)
+            vdist.broadcast_module(self.netd)
         self.gt_flow = self.pre_flow = None
 
     def set_input(self, data, gt_flow=None, pre_flow=None):

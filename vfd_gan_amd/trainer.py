@@ -12,6 +12,21 @@ from . import functional as F
 from .lib.args import Args
 
 
+def build_model(args, dataloader):
+    """MODEL LOAD of reference trainer.py:16-40."""
+    if args.model == 'mygan':
+        from .models.mygannet import MyGAN
+        return MyGAN(args, dataloader)
+    if args.model == 'anogan':
+        from .models.anogan import AnoGAN
+        return AnoGAN(args, dataloader)
+    if args.model == 'ganomaly':
+        from .models.ganomaly import Ganomaly
+        return Ganomaly(args, dataloader)
+    print("\n %s is None." % (args.model))
+    exit()
+
+
 def main(args):
     # -- DATA LOAD --
     from .lib.data import DataLoader
@@ -20,19 +35,7 @@ def main(args):
     # -- MODEL LOAD --
     if vdist.rank() == 0:
         print("--Load model--")
-    if args.model == 'mygan':
-        from .models.mygannet import MyGAN
-        model = MyGAN(args, dataloader)
-    elif args.model == 'anogan':
-        from .models.anogan import AnoGAN
-        model = AnoGAN(args, dataloader)
-    elif args.model == 'ganomaly':
-        from .models.ganomaly import Ganomaly
-        model = Ganomaly(args, dataloader)
-    else:
-        print("\n %s is None." % (args.model))
-        exit()
-
+    model = build_model(args, dataloader)
     model.train()
     return model
 
