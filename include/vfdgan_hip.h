@@ -119,6 +119,13 @@ int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* pack
  * on, so that they follow the dispatch rules instead of restating them. */
 int vfd_conv_kernel_name(const vfd_conv_desc* d, int want_stats, char* buf, size_t n);
 
+/* Dispatch switch of the halo-tiled kernel (conv_halo.hip: unit-input-stride layers with <= 64 output channels, bf16):
+ * 0 = default rules (layers with >= 512 work items), 1 = never (every layer goes to conv_igemm / conv_small: the A/B
+ * baseline of the layer benchmarks and of the parity tests that compare the two kernels on identical inputs),
+ * 2 = whenever the shape is eligible, however small (tests).  Returns the previous mode.  Process-wide; not meant
+ * to be flipped while launches are in flight on other threads. */
+int vfd_conv_set_halo_mode(int mode);
+
 /* Filter gradient.  Computes, for the conv described by `d` (same desc as forward),
  *     dWp[r][t][c] = sum_{n,q} S[n,q][r] * G[n, q*s-p+t][c]
  * with (S,G) = (dy, x) for transposed = 0 and (x, dy) for transposed = 1, i.e. in the packed layout of

@@ -198,7 +198,7 @@ def audit_file(src, outdir):
 
 
 def main(argv):
-    files = argv or [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_wgrad.hip", "conv_small.hip")]
+    files = argv or [os.path.join(CSRC, f) for f in ("conv_igemm.hip", "conv_halo.hip", "conv_wgrad.hip", "conv_small.hip")]
     bad = 0
     with tempfile.TemporaryDirectory() as td:
         for f in files:

@@ -11,6 +11,17 @@ import torch  # noqa: E402
 
 from vfd_gan_amd import _lib, functional as F  # noqa: E402
 
+# 3-D layers of anogan at 16x112x112 (BASELINE configs[2]): name, Cin, Cout, (D,H,W) in, k, s, p, transposed
+LAYERS3D = [
+    ("D.l1 32->64 k3 @16x112", 32, 64, (16, 112, 112), 3, 1, 1, False),
+    ("D.l1 64->64 k3 @16x112", 64, 64, (16, 112, 112), 3, 1, 1, False),
+    ("D.l2 64->128 k3 @8x56", 64, 128, (8, 56, 56), 3, 1, 1, False),
+    ("D.l2 128->128 k3 @8x56", 128, 128, (8, 56, 56), 3, 1, 1, False),
+    ("D.l2 128->256 k3 @4x28", 128, 256, (4, 28, 28), 3, 1, 1, False),
+    ("G.l3 128->64 convT k3s1 @8x56", 128, 64, (8, 56, 56), 3, 1, 1, True),
+    ("G.l3 64->64 k3 @8x56", 64, 64, (8, 56, 56), 3, 1, 1, False),
+]
+
 LAYERS = [
     # name, Cin, Cout, H(in), k, s, p, transposed
     ("enc.init 3->64 k4s2 @112", 3, 64, 112, 4, 2, 1, False),
@@ -45,36 +56,44 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
+    ap.add_argument("--set", default="ganomaly", choices=["ganomaly", "anogan"], help="ganomaly: 2-D pyramid, 512 frames; anogan: 3-D layers, 32 clips")
+    ap.add_argument("--halo", type=int, default=0, help="vfd_conv_set_halo_mode: 0 default rules, 1 never (conv_igemm), 2 always")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     dev = torch.device("cuda", 0)
     lib = _lib.load()
-    N = a.frames
+    lib.vfd_conv_set_halo_mode(a.halo)
+    N = a.frames if a.set == "ganomaly" else 32
+    layers = LAYERS if a.set == "ganomaly" else LAYERS3D
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print("%-34s %10s %8s | %10s %8s | %10s %8s" % ("layer", "fwd us", "TF/s", "dgrad us", "TF/s", "wgrad us", "TF/s"))
-    for name, cin, cout, h, k, s, p, tr in LAYERS:
+    for name, cin, cout, h, k, s, p, tr in layers:
         if a.only and a.only not in name:
             continue
-        ho = (h - 1) * s - 2 * p + k if tr else (h + 2 * p - k) // s + 1
-        x = torch.randn(N, 1, h, h, F.cpad(cin), device=dev).to(dt)
+        dims = (1, h, h) if isinstance(h, int) else h
+        nd3 = not isinstance(h, int)
+        kk, ss, pp = ((k, k, k), (s, s, s), (p, p, p)) if nd3 else ((1, k, k), (1, s, s), (0, p, p))
+        odims = tuple(((dims[i] - 1) * ss[i] - 2 * pp[i] + kk[i]) if tr else ((dims[i] + 2 * pp[i] - kk[i]) // ss[i] + 1) for i in range(3))
+        x = torch.randn((N,) + dims + (F.cpad(cin),), device=dev).to(dt)
         x[..., cin:] = 0
-        gy = torch.randn(N, 1, ho, ho, F.cpad(cout), device=dev).to(dt)
+        gy = torch.randn((N,) + odims + (F.cpad(cout),), device=dev).to(dt)
         gy[..., cout:] = 0
-        w = torch.nn.Parameter(torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), device=dev) * 0.05)
-        T = k * k
+        w = torch.nn.Parameter(torch.randn(((cin, cout) if tr else (cout, cin)) + (kk if nd3 else kk[1:]), device=dev) * 0.05)
+        T = kk[0] * kk[1] * kk[2]
         A, B = (cin, cout) if tr else (cout, cin)
         pk_f = F._packed_filter(w, dt, bool(tr), A, B, T)
         pk_d = F._packed_filter(w, dt, not tr, A, B, T)
         y = torch.empty_like(gy)
         gx = torch.empty_like(x)
-        d_f = F._make_desc(N, (1, h, h), cin, (1, ho, ho), cout, (1, k, k), (1, s, s), (0, p, p), tr, dt)
-        d_d = F._make_desc(N, (1, ho, ho), cout, (1, h, h), cin, (1, k, k), (1, s, s), (0, p, p), not tr, dt)
+        d_f = F._make_desc(N, dims, cin, odims, cout, kk, ss, pp, tr, dt)
+        d_d = F._make_desc(N, odims, cout, dims, cin, kk, ss, pp, not tr, dt)
         nsplit, nbytes = ctypes.c_int32(), ctypes.c_size_t()
         _lib.check(lib.vfd_wgrad_workspace(ctypes.byref(d_f), ctypes.byref(nsplit), ctypes.byref(nbytes)))
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         gw = torch.empty_like(w)
         st = _lib.stream()
-        flops = 2.0 * N * (h * h if tr else ho * ho) * T * cin * cout
+        px_in, px_out = dims[0] * dims[1] * dims[2], odims[0] * odims[1] * odims[2]
+        flops = 2.0 * N * (px_in if tr else px_out) * T * cin * cout
         def wsp(d):
             need = ctypes.c_size_t()
             _lib.check(lib.vfd_conv_workspace(ctypes.byref(d), 0, ctypes.byref(need)))

@@ -37,6 +37,10 @@ void vfd_set_error(const char* fmt, ...);
 int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, bool want_stats,
                        bool query, hipStream_t st);
 
+// conv_halo.hip: same return convention; unit-input-stride layers with <= 64 output channels (bf16)
+int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+                      const void* mul_src, int mul_act, float mul_slope, bool query, hipStream_t st);
+
 static inline int cpad(int c) { return (c + 7) & ~7; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -66,6 +70,42 @@ __device__ __forceinline__ void fdivmod(uint32_t m, const FastDiv& f, uint32_t& 
   q = fdiv(m, f);
   r = m - q * f.d;
 }
+
+// ---- per-dimension description of the taps of one output class of a (transposed) convolution -----------------
+//     regular    : in = q*s - p + t            (t = tap, all k taps)          out = q
+//     transposed : in = q + c0 - t,  k = k0 + t*s, k0 = (r+p)%s, c0 = (r+p-k0)/s,  out = q*s + r
+struct DimClass {
+  int nk;   // number of taps
+  int k0;   // first filter index
+  int ks;   // filter index step
+  int c0;   // input coordinate offset
+  int cs;   // input coordinate step per tap (+1 regular, -1 transposed)
+  int a;    // input coordinate multiplier of q
+  int so;   // output coordinate multiplier of q
+  int r;    // output coordinate offset
+  int Q;    // number of q along this dim
+  FastDiv fq;  // division by Q (pixel index decomposition)
+};
+
+static inline DimClass make_dim_host(int transposed, int r, int k, int s, int p, int O) {
+  DimClass d;
+  if (!transposed) {
+    d.nk = k; d.k0 = 0; d.ks = 1; d.c0 = -p; d.cs = 1; d.a = s; d.so = 1; d.r = 0; d.Q = O;
+  } else {
+    d.k0 = (r + p) % s;
+    d.nk = (d.k0 < k) ? (k - d.k0 + s - 1) / s : 0;
+    d.ks = s;
+    d.c0 = (r + p - d.k0) / s;
+    d.cs = -1;
+    d.a = 1;
+    d.so = s;
+    d.r = r;
+    d.Q = (O > r) ? (O - r + s - 1) / s : 0;
+  }
+  d.fq = make_fastdiv((uint32_t)d.Q);
+  return d;
+}
+
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -188,7 +228,10 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(lds_char_t*)p;
 }
 __device__ __forceinline__ void dma16_to_lds(const void* gsrc, uint32_t lds_dst_uniform) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst_uniform) : "memory");
+  // readfirstlane: a no-op for a value the compiler already holds in an SGPR; where it cannot prove uniformity it would
+  // otherwise hand the "s" operand a VGPR
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(dst) : "memory");
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

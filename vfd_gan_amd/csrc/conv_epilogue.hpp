@@ -1,0 +1,211 @@
+// Epilogue shared by the MFMA convolution kernels (conv_igemm.hip, conv_halo.hip): bias, BatchNorm partial sums,
+// activation, optional multiply by act'(mul_src), channels-last store.
+//
+// Accumulator layout (both kernels): wave w owns channels [wave_c0, +NI*16) x tile rows (pixels) [wave_p0, +NJ*16) with
+// wave_c0 = (w % WAVES_C) * NI*16, wave_p0 = (w / WAVES_C) * NJ*16; acc[i][j][r] = channel wave_c0 + 16 i + 4 (lane>>4) + r
+// of tile row wave_p0 + 16 j + (lane & 15)   (v_mfma_f32_16x16x*: channels are the MFMA row dimension).
+// `out_offset(tile_row)` -> element offset of that pixel's channel 0 in y, or -1 (row outside the tensor);
+// `row_valid(tile_row)` == (out_offset(tile_row) >= 0), in a form that needs no address arithmetic.
+// The staging LDS (`smem`, RING_BYTES, all DMAs drained by the caller) is reused.
+#pragma once
+#include "common.hpp"
+#include <type_traits>
+
+struct EpiP {
+  void* y;
+  const float* bias;
+  float* stats;          // [VFD_STATS_REPLICAS][2][Cop] or null
+  int Cop, Cout;
+  int act;
+  float slope;
+  const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape)
+  int mul_act;
+  float mul_slope;
+};
+
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, typename OutOff, typename RowValid>
+__device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], const EpiP& p, int n0, int stats_replica,
+                                              OutOff out_offset, RowValid row_valid) {
+  constexpr int TILE_C = WAVES_C * NI * 16;
+  constexpr int TILE_P = WAVES_P * NJ * 16;
+  constexpr int NWAVES = WAVES_C * WAVES_P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_c0 = (wave % WAVES_C) * (NI * 16);
+  const int wave_p0 = (wave / WAVES_C) * (NJ * 16);
+  const int cq = (lane >> 4) * 4;
+  // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time; the activation is
+  // dispatched ONCE around the loops: a per-value switch is replicated, branches included, in every unrolled copy)
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+  const bool want_stats = p.stats != nullptr;
+  // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
+  // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
+  // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
+  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
+    // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
+  constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
+                     : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
+  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64 && NH > 0;
+  constexpr int HALF_P = VIA_LDS ? TILE_P / NH : TILE_P;
+  constexpr int OUT_BYTES = VIA_LDS ? HALF_P * TILE_C * 2 : 0;
+  static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= RING_BYTES, "epilogue LDS exceeds the staging LDS");
+  // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
+  // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
+  // same 2*Cout addresses; bn_from_sums folds the replicas).
+  float* red = reinterpret_cast<float*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
+  long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
+  long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
+  bool pvalid[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wave_p0 + j * 16 + (lane & 15);
+    pvalid[j] = row_valid(row);      // cheap form of out_offset(row) >= 0 (statistics mask)
+    if constexpr (!VIA_LDS) opix[j] = out_offset(row);
+  }
+  if (VIA_LDS || want_stats) __syncthreads();      // every wave is done reading the last stage
+  if constexpr (VIA_LDS) {
+    for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(r);
+  }
+  // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
+  // accumulator tile across a store phase); the statistics of all sub-tiles are taken in pass 0
+  auto body = [&](auto actf, auto hc) {
+    constexpr int H = decltype(hc)::value;
+    constexpr int JN = VIA_LDS ? NJ / NH : NJ;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = n0 + wave_c0 + i * 16 + cq;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
+      }
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const bool emit = j >= H * JN && j < (H + 1) * JN;     // compile-time after unrolling
+        if (!emit && H != 0) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[i][j][r] + b4[r];
+          if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+          v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
+        }
+        if (!emit) continue;
+        if constexpr (VIA_LDS) {
+          // 8-byte unit u of tile row (pixel) with row & 15 == n sits at slot u ^ n: the 16 rows of one ds_write_b64
+          // group land on 16 different bank pairs, and a pixel's 16-byte chunk c is found whole at c ^ (n >> 1)
+          const int n = lane & 15;
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(smem + ((wave / WAVES_C) * (JN * 16) + (j - H * JN) * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
+        } else {
+          if (opix[j] >= 0 && c < p.Cop) {
+            T* dst = yg + opix[j] + c;
+            if (p.mul_src != nullptr) {
+              const T* ms = reinterpret_cast<const T*>(p.mul_src) + opix[j] + c;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(Elem<T>::ld(ms + r), p.mul_act, p.mul_slope);
+            }
+            if constexpr (sizeof(T) == 2) {
+              uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+              *reinterpret_cast<uint2*>(dst) = o;
+            } else {
+              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
+        }
+      }
+      if (H == 0 && want_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a = s1[r], b = s2[r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          if ((lane & 15) == 0) {
+            const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
+            red[cl * WAVES_P + (wave / WAVES_C)] = a;
+            red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
+          }
+        }
+      }
+    }
+  };
+  // store phase of pass h: the rows of pixel half h leave LDS as whole pixel rows, 16 bytes per lane
+  auto store_rows = [&](int h) {
+    constexpr int CPRW = TILE_C / 8;          // 16-byte chunks per tile row
+    constexpr int RPW = 64 / CPRW;            // tile rows per wave-instruction
+    constexpr int NIT = HALF_P / RPW;         // wave-instructions per pass
+    constexpr int U = NH == 1 ? 4 : 2;        // rows in flight per lane (two passes: half the waves still hold their tile)
+    const int c = lane % CPRW;
+    const bool cok = n0 + c * 8 < p.Cop;
+    const bf16_t* ms = reinterpret_cast<const bf16_t*>(p.mul_src);
+    for (int it0 = wave; it0 < NIT; it0 += U * NWAVES) {
+      long long off[U];
+      uint4 v[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * NWAVES;
+        const int lr = it * RPW + lane / CPRW;               // row of this pass's LDS image = (pixel wave, sub-tile, pixel)
+        const int tr = (lr / (HALF_P / WAVES_P)) * (TILE_P / WAVES_P) + h * (HALF_P / WAVES_P) + lr % (HALF_P / WAVES_P);
+        off[u] = (it < NIT && cok) ? orow[tr] : -1;
+      }
+      if (ms != nullptr) {      // the producer's activation output at the same positions: all U loads issued together
+#pragma unroll
+        for (int u = 0; u < U; ++u) mv[u] = *reinterpret_cast<const uint4*>(ms + (off[u] >= 0 ? off[u] + n0 + c * 8 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int it = it0 + u * NWAVES;
+        const int row = (it < NIT ? it : wave % NIT) * RPW + lane / CPRW, n = row & 15;
+        v[u] = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
+        if (n & 1) v[u] = make_uint4(v[u].z, v[u].w, v[u].x, v[u].y);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (ms != nullptr) {
+          float f[8], m[8];
+          load8(reinterpret_cast<const bf16_t*>(&v[u]), f);
+          load8(reinterpret_cast<const bf16_t*>(&mv[u]), m);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul_act, p.mul_slope);
+          store8(reinterpret_cast<bf16_t*>(&v[u]), f);
+        }
+        if (off[u] >= 0) *reinterpret_cast<uint4*>(yg + off[u] + n0 + c * 8) = v[u];
+      }
+    }
+  };
+  auto dispatch_body = [&](auto hc) {
+    const float slope = p.slope;
+    constexpr bool FAST = sizeof(T) == 2;     // bf16 output: v_exp/v_rcp forms are exact to far below half an ulp
+    switch (p.act) {
+      case VFD_ACT_LRELU: body([slope](float t) { return t > 0.f ? t : t * slope; }, hc); break;
+      case VFD_ACT_SIGMOID: body([](float t) { return FAST ? fast_sigmoid(t) : 1.f / (1.f + __expf(-t)); }, hc); break;
+      case VFD_ACT_TANH: body([](float t) { return FAST ? fast_tanh(t) : tanhf(t); }, hc); break;
+      default: body([](float t) { return t; }, hc); break;
+    }
+  };
+  dispatch_body(std::integral_constant<int, 0>());
+  if constexpr (!VIA_LDS) {
+    if (want_stats) __syncthreads();
+  } else {
+    __syncthreads();
+    store_rows(0);
+    if constexpr (NH == 2) {
+      __syncthreads();
+      dispatch_body(std::integral_constant<int, 1>());
+      __syncthreads();
+      store_rows(1);
+    }
+  }
+  if (want_stats) {
+    float* rep = p.stats + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
+      const int which = t / TILE_C, cl = t - which * TILE_C;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
+      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);
+    }
+  }
+}

@@ -1,0 +1,317 @@
+// Halo-tiled convolution on MFMA for layers whose taps walk the INPUT with unit stride (gfx950, bf16):
+// stride-1 Conv3d / Conv2d, stride-1 transposed convolutions, and every output class of a strided transposed
+// convolution (= the data gradient of a strided convolution), with at most 3 taps per dimension and class.
+// These are the 32..64-channel 3-D layers of anogan's NetD / NetG (reference models/anogan.py:62-72, 84-93), the
+// (1,3,3) / (3,1,1) factors of the (2+1)D blocks (models/spatiotempconv.py:45-55) and the 64-channel ends of the
+// ganomaly pyramid (models/ganomaly.py:100-118).
+//
+// Why a second MFMA kernel: conv_igemm gathers the [pixel][K-slice] operand tap by tap from global memory, i.e. every
+// input pixel crosses the global->LDS path once per tap (27x for a 3x3x3 filter).  With <= 64 output channels per tile
+// the MFMA work per staged byte is too small for that path (80 B/clk/CU wanted, 28..54 delivered): those
+// layers ran at 360..620 TFLOP/s.  Here a workgroup stages the input ONCE per 32-channel chunk as a halo block
+// (TD+kd-1) x (TH+kh-1) x (16+kw-1) pixels and reads the B fragments of every tap from it at shifted rows: the
+// im2col happens in the LDS addressing.  Only the [TILE_C][32] filter slice of a tap streams through a 2-deep ring.
+//
+//   LDS      halo rows of 64 B (one pixel's 32-channel chunk), 16-byte slot c of row r stored at c ^ 2*((r>>2)&1):
+//            conflict-free for ds_read_b128 fragments of 16 consecutive rows at ANY row alignment (the tap shifts
+//            move the fragment's first row arbitrarily; checked against the lane groups of MI355X_MICROARCH.md §LDS);
+//            filter stage [TILE_C rows][64 B], same swizzle.
+//   waves    4 per workgroup, each 64 pixels (4 groups of 16 consecutive w) x TILE_C channels, 3 workgroups per CU
+//            (49.7 KB LDS): while one loads its next halo block the others compute.
+//   sync     one raw s_barrier per tap, `s_waitcnt vmcnt(0)` (every DMA issued one tap earlier) — no counted waits:
+//            a halo block takes a varying number of DMA instructions per wave.
+#include "common.hpp"
+#include "conv_epilogue.hpp"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+struct HaloP {
+  const void* x;
+  const void* w;
+  EpiP e;
+  int N, Di, Hi, Wi, Cip;
+  int Do, Ho, Wo;
+  int kh, kw;            // full filter extents (tap index arithmetic)
+  int Kw;                // packed filter row length in elements = kd*kh*kw*Cip
+  int transposed, sh, sw;   // class decomposition: cls = (rd*sh + rh)*sw + rw (transposed only)
+  int ncls, ny;          // output classes, channel tiles
+  int ntd, nth, ntw;     // pixel tiles per dimension (class 0, the largest)
+  int per_xcd;           // workgroups per XCD group (grid = 8 * per_xcd)
+  long long nwork;       // ncls * ny * N * ntd * nth * ntw
+  FastDiv fgroup, fntw, fnth, fntd;
+  DimClass dims[3][4];   // [d,h,w][class], stride <= 4
+};
+
+__device__ uint4 g_halo_zero_page[4];
+
+template <int TILE_C, int TD, int TH>
+struct HaloCfg {
+  static constexpr int NI = TILE_C / 16;
+  static constexpr int NJ = 4;
+  static constexpr int HD_MAX = TD > 1 ? TD + 2 : 1;          // frames (TD == 1) carry no depth halo
+  static constexpr int ROWS_MAX = HD_MAX * (TH + 2) * 18;
+  static constexpr int HALO_BYTES = (ROWS_MAX + 15) / 16 * 1024;
+  static constexpr int FSTAGE = TILE_C * 64;
+  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 4 + 256 * 8;
+  static constexpr int LDS = (HALO_BYTES + 2 * FSTAGE > EPI_BYTES) ? HALO_BYTES + 2 * FSTAGE : EPI_BYTES;
+  static constexpr int NHW = ((ROWS_MAX + 15) / 16 + 3) / 4;  // halo DMA instructions per wave (upper bound)
+};
+
+template <int TILE_C, int TD, int TH>
+__global__ __launch_bounds__(256, 3) void conv_halo_kernel(const HaloP p) {
+  using C = HaloCfg<TILE_C, TD, TH>;
+  constexpr int NI = C::NI, NJ = C::NJ;
+  static_assert(TD * TH == 16, "a tile is 16 groups of 16 pixels");
+  __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- work item: (sample, pixel tile, class, channel tile).  Workgroups go round-robin to the 8 XCDs (id % 8): each
+  // XCD takes a CONTIGUOUS range of work items, so tiles that share halo planes (and a tile's classes / channel tiles,
+  // which read the same pixels) meet in one L2.
+  const long long item = (long long)(blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+  if (item >= p.nwork) return;
+  uint32_t t = (uint32_t)item, jitem, itw, ith, itd;
+  fdivmod(t, p.fgroup, t, jitem);
+  fdivmod(t, p.fntw, t, itw);
+  fdivmod(t, p.fnth, t, ith);
+  fdivmod(t, p.fntd, t, itd);
+  const int n = (int)t;
+  int cls = (int)jitem / p.ny;
+  const int ytile = (int)jitem - cls * p.ny;
+  const int cls_id = cls;
+  const int rw = p.transposed ? cls % p.sw : 0;
+  if (p.transposed) cls /= p.sw;
+  const int rh = p.transposed ? cls % p.sh : 0;
+  if (p.transposed) cls /= p.sh;
+  const int rd = p.transposed ? cls : 0;
+  const DimClass dd = p.dims[0][rd], dh = p.dims[1][rh], dw = p.dims[2][rw];
+  const int q0d = (int)itd * TD, q0h = (int)ith * TH, q0w = (int)itw * 16;
+  if (q0d >= dd.Q || q0h >= dh.Q || q0w >= dw.Q) return;      // smaller classes have fewer tiles (uniform per workgroup)
+  const int n0 = ytile * TILE_C;
+  const int ntaps = dd.nk * dh.nk * dw.nk;
+  const int nchunks = (p.Cip + 31) >> 5;
+  const int nsteps = ntaps * nchunks;
+
+  // halo block of this tile: input coordinates [o, o + H) per dimension
+  const int HD = TD + dd.nk - 1, HH = TH + dh.nk - 1, HW = 16 + dw.nk - 1;
+  const int od0 = q0d + dd.c0 - (dd.cs < 0 ? dd.nk - 1 : 0);
+  const int oh0 = q0h + dh.c0 - (dh.cs < 0 ? dh.nk - 1 : 0);
+  const int ow0 = q0w + dw.c0 - (dw.cs < 0 ? dw.nk - 1 : 0);
+  const int rows = HD * HH * HW;
+  const int ninst = (rows + 15) >> 4;
+
+  constexpr uint32_t NONE = 0xffffffffu;
+  const int slot = lane & 3;
+  // ---- per-lane filter row (this wave's DMA instruction = 16 rows of the stage): granule offset of (row, tap 0, ch 0)
+  uint32_t wrow = NONE;
+  {
+    const int row = wave * 16 + (lane >> 2);
+    const int co = n0 + row;
+    if (wave < NI && co < p.e.Cout) wrow = (uint32_t)(((long long)co * p.Kw) >> 3);
+  }
+  // source-side swizzle: physical slot s of LDS row r holds logical chunk s ^ 2*((r>>2)&1); every DMA instruction starts
+  // at a multiple of 16 rows, so the row's bit 2 is bit 4 of the lane
+  const int lchunk = slot ^ (((lane >> 4) & 1) << 1);
+  const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const uint32_t halo_base = smem_base, filt_base = smem_base + C::HALO_BYTES;
+  const char* zero = reinterpret_cast<const char*>(g_halo_zero_page);
+  const char* xg = reinterpret_cast<const char*>(p.x);
+  const char* wg = reinterpret_cast<const char*>(p.w);
+
+  // ---- per-lane halo sources (16-byte granule offsets of the pixel's channel 0, or NONE): once per tile
+  uint32_t hoff[C::NHW];
+  {
+    const float inv_hw = 1.0f / (float)(HH * HW), inv_w = 1.0f / (float)HW;
+    const int gpp = p.Cip >> 3;   // granules per pixel
+#pragma unroll
+    for (int k = 0; k < C::NHW; ++k) {
+      const int r = (wave + 4 * k) * 16 + (lane >> 2);
+      uint32_t off = NONE;
+      if (r < rows) {
+        const int dz = (int)(((float)r + 0.5f) * inv_hw);
+        const int rem = r - dz * HH * HW;
+        const int hy = (int)(((float)rem + 0.5f) * inv_w);
+        const int wx = rem - hy * HW;
+        const int id = od0 + dz, ih = oh0 + hy, iw = ow0 + wx;
+        if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+          off = (uint32_t)(((n * p.Di + id) * p.Hi + ih) * p.Wi + iw) * (uint32_t)gpp;
+      }
+      hoff[k] = off;
+    }
+  }
+  auto issue_halo = [&](int chunk) __attribute__((always_inline)) {
+    const int ch = chunk * 32 + lchunk * 8;
+    const bool chok = ch < p.Cip;
+#pragma unroll
+    for (int k = 0; k < C::NHW; ++k) {
+      const int inst = wave + 4 * k;       // wave-uniform
+      if (inst < ninst) {
+        const char* src = (chok && hoff[k] != NONE) ? xg + ((size_t)hoff[k] << 4) + ch * 2 : zero;
+        dma16_to_lds(src, halo_base + inst * 1024);
+      }
+    }
+  };
+  // filter slice of tap (td, th, tw), channel chunk `chunk` -> stage fs
+  auto issue_filter = [&](int fs, int td, int th, int tw, int chunk) __attribute__((always_inline)) {
+    if (wave < NI) {
+      const int tapidx = ((dd.k0 + td * dd.ks) * p.kh + (dh.k0 + th * dh.ks)) * p.kw + (dw.k0 + tw * dw.ks);
+      const int ch = chunk * 32 + lchunk * 8;
+      const char* src = (wrow != NONE && ch < p.Cip) ? wg + ((size_t)(wrow + (uint32_t)(tapidx * (p.Cip >> 3))) << 4) + ch * 2 : zero;
+      dma16_to_lds(src, filt_base + fs * C::FSTAGE + wave * 1024);
+    }
+  };
+
+  // ---- fragment addressing
+  const int l15 = lane & 15, c16 = (lane >> 4) << 4;
+  // A (filter stage): row = 16 i + l15, rows start at multiples of 16: swizzle bit = bit 2 of l15
+  const int a_off = (l15 << 6) + (c16 ^ ((l15 & 4) << 3));
+  // B (halo): first row of pixel group j of this wave at tap shift 0
+  int brow[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int g = wave * 4 + j;
+    brow[j] = ((g / TH) * HH + (g % TH)) * HW + l15;
+  }
+
+  f32x4 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop: one tap of one channel chunk per iteration.
+  // (A variant that prefetched the next tap's fragments into a second register set and loaded the next halo block behind
+  // the last tap measured SLOWER: 804 vs 825 TFLOP/s on the 64->64 3-D layer, 377 vs 453 on the 2-D transposed pyramid
+  // layer — with three workgroups per CU a wave's LDS latency is already covered by the other workgroups' MFMAs, and the
+  // extra 40 registers and control flow cost more than the overlap gains.)
+  issue_halo(0);
+  issue_filter(0, 0, 0, 0, 0);
+  int td = 0, th = 0, tw = 0, chunk = 0, fs = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    // next step's position
+    int ntw_ = tw + 1, nth_ = th, ntd_ = td, nchunk = chunk;
+    if (ntw_ == dw.nk) { ntw_ = 0; if (++nth_ == dh.nk) { nth_ = 0; if (++ntd_ == dd.nk) { ntd_ = 0; ++nchunk; } } }
+    const bool new_chunk = (td | th | tw) == 0 && chunk > 0;
+    // this step's filter slice (issued one step ago) and, in step 0, the first halo block have landed; every wave is done
+    // with the LDS reads of the previous step (the barrier waits for no counter: retire them explicitly)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (new_chunk) issue_halo(chunk);                 // the old block is dead: all waves passed the barrier above
+    if (s + 1 < nsteps) issue_filter(fs ^ 1, ntd_, nth_, ntw_, nchunk);
+    if (new_chunk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    {
+      const int sd_ = dd.cs > 0 ? td : dd.nk - 1 - td, sh_ = dh.cs > 0 ? th : dh.nk - 1 - th, sw_ = dw.cs > 0 ? tw : dw.nk - 1 - tw;
+      const int shift = (sd_ * HH + sh_) * HW + sw_;          // wave-uniform row shift of this tap
+      const char* ft = smem + C::HALO_BYTES + fs * C::FSTAGE;
+      bf16x8 a[NI], b[NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ft + i * 1024 + a_off);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int v = brow[j] + shift;
+        b[j] = *reinterpret_cast<const bf16x8*>(smem + ((v << 6) + (c16 ^ ((v & 4) << 3))));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    fs ^= 1;
+    td = ntd_; th = nth_; tw = ntw_; chunk = nchunk;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // ---- epilogue (conv_epilogue.hpp): tile row r = 16 g + wl, g = TH * dl + hl
+  auto row_q = [&](int r, int& qd, int& qh, int& qw) __attribute__((always_inline)) {
+    const int g = r >> 4;
+    qd = q0d + g / TH; qh = q0h + g % TH; qw = q0w + (r & 15);
+    return qd < dd.Q && qh < dh.Q && qw < dw.Q;
+  };
+  auto out_offset = [&](int r) __attribute__((always_inline)) -> long long {
+    int qd, qh, qw;
+    if (!row_q(r, qd, qh, qw)) return -1;
+    return (((long long)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r) * p.e.Cop;
+  };
+  conv_epilogue<bf16_t, 1, 4, NI, NJ, C::LDS>(smem, acc, p.e, n0, (int)(item & 0x7fffffff) + cls_id, out_offset,
+                                             [&](int r) { int a_, b_, c_; return row_q(r, a_, b_, c_); });
+}
+
+template <int TILE_C, int TD, int TH>
+int launch_halo(const HaloP& p, hipStream_t st) {
+  const long long nwg = (long long)p.per_xcd * 8;
+  if (nwg >= 0x7fffffffLL) return 0;
+  hipLaunchKernelGGL((conv_halo_kernel<TILE_C, TD, TH>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
+
+}  // namespace
+
+static int g_halo_mode = -1;     // -1: not yet read from the environment (VFD_NO_HALO=1 -> mode 1)
+
+extern "C" int vfd_conv_set_halo_mode(int mode) {
+  const int prev = g_halo_mode < 0 ? (getenv("VFD_NO_HALO") != nullptr ? 1 : 0) : g_halo_mode;
+  g_halo_mode = (mode >= 0 && mode <= 2) ? mode : 0;
+  return prev;
+}
+
+// 1 = handled (or, with query, would be handled), 0 = not a halo shape, < 0 = launch error
+int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+                      const void* mul_src, int mul_act, float mul_slope, bool query, hipStream_t st) {
+  if (g_halo_mode < 0) g_halo_mode = getenv("VFD_NO_HALO") != nullptr ? 1 : 0;
+  if (g_halo_mode == 1 || d->dtype != VFD_BF16) return 0;
+  const int k[3] = {d->kd, d->kh, d->kw}, s[3] = {d->sd, d->sh, d->sw}, pp[3] = {d->pd, d->ph, d->pw};
+  const int O[3] = {d->Do, d->Ho, d->Wo};
+  for (int i = 0; i < 3; ++i) {
+    if (!d->transposed && s[i] != 1) return 0;                      // the taps must walk the input with unit stride
+    if (d->transposed && (s[i] > 4 || (k[i] + s[i] - 1) / s[i] > 3)) return 0;
+    if (!d->transposed && k[i] > 3) return 0;
+  }
+  if (d->Cout > 64 || d->Cin < 25) return 0;      // wider outputs: conv_igemm's 128/256-channel tiles; thin inputs: conv_small / igemm
+  HaloP p;
+  p.x = x; p.w = packed;
+  p.e.y = y; p.e.bias = bias; p.e.stats = stats; p.e.Cop = cpad(d->Cout); p.e.Cout = d->Cout; p.e.act = d->act; p.e.slope = d->slope;
+  p.e.mul_src = mul_src; p.e.mul_act = mul_act; p.e.mul_slope = mul_slope;
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = cpad(d->Cin);
+  p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.kh = d->kh; p.kw = d->kw;
+  p.Kw = d->kd * d->kh * d->kw * p.Cip;
+  p.transposed = d->transposed; p.sh = d->sh; p.sw = d->sw;
+  p.ncls = d->transposed ? d->sd * d->sh * d->sw : 1;
+  int Q0[3];
+  for (int i = 0; i < 3; ++i) {
+    const int nr = d->transposed ? s[i] : 1;
+    for (int r = 0; r < nr; ++r) p.dims[i][r] = make_dim_host(d->transposed, r, k[i], s[i], pp[i], O[i]);
+    Q0[i] = p.dims[i][0].Q;
+    for (int r = 0; r < nr; ++r)
+      if (p.dims[i][r].nk < 1) return 0;           // a class without taps (k < s): leave it to the general kernel
+  }
+  const bool frames = Q0[0] == 1 && d->Di == 1;
+  if (!frames && Q0[0] < 3) return 0;              // 2-deep volumes would leave half of a 4-deep tile empty
+  if (Q0[2] < 12 || Q0[1] < (frames ? 12 : 3)) return 0;
+  const int TD = frames ? 1 : 4, TH = frames ? 16 : 4;
+  p.ntd = (Q0[0] + TD - 1) / TD; p.nth = (Q0[1] + TH - 1) / TH; p.ntw = (Q0[2] + 15) / 16;
+  const int tile_c = d->Cout > 32 ? 64 : 32;
+  p.ny = (d->Cout + tile_c - 1) / tile_c;
+  const long long tiles = (long long)d->N * p.ntd * p.nth * p.ntw;
+  p.nwork = tiles * p.ncls * p.ny;
+  if (p.nwork < 512 && g_halo_mode != 2) return 0;     // few tiles: conv_igemm's split-K paths
+  // 32-bit granule addressing (as conv_igemm)
+  const long long in_px = (long long)d->N * d->Di * d->Hi * d->Wi;
+  if (in_px >= 0x7fffffffLL || in_px * p.Cip / 8 >= 0xffffffffLL || (long long)d->Cout * p.Kw / 8 >= 0xffffffffLL) return 0;
+  if (query) return 1;
+  p.per_xcd = (int)((p.nwork + 7) / 8);
+  p.fgroup = make_fastdiv((uint32_t)(p.ncls * p.ny));
+  p.fntw = make_fastdiv((uint32_t)p.ntw); p.fnth = make_fastdiv((uint32_t)p.nth); p.fntd = make_fastdiv((uint32_t)p.ntd);
+  if (p.nwork >= 0x7fffffffLL) return 0;
+  if (frames) return tile_c == 64 ? launch_halo<64, 1, 16>(p, st) : launch_halo<32, 1, 16>(p, st);
+  return tile_c == 64 ? launch_halo<64, 4, 4>(p, st) : launch_halo<32, 4, 4>(p, st);
+}

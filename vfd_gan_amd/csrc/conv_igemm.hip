@@ -17,23 +17,11 @@
 //     regular    : in = q*s - p + t            (t = tap, all k taps)          out = q
 //     transposed : in = q + c0 - t,  k = k0 + t*s, k0 = (r+p)%s, c0 = (r+p-k0)/s,  out = q*s + r
 #include "common.hpp"
+#include "conv_epilogue.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
-
-struct DimClass {  // per-dimension description of the taps of one output class
-  int nk;   // number of taps
-  int k0;   // first filter index
-  int ks;   // filter index step
-  int c0;   // input coordinate offset
-  int cs;   // input coordinate step per tap (+1 regular, -1 transposed)
-  int a;    // input coordinate multiplier of q
-  int so;   // output coordinate multiplier of q
-  int r;    // output coordinate offset
-  int Q;    // number of q along this dim
-  FastDiv fq;  // division by Q (pixel index decomposition)
-};
 
 constexpr int DIM_TAB = 8;   // per-dimension output classes with a host-built description (stride <= 8; else built on the device)
 
@@ -91,25 +79,6 @@ __device__ __forceinline__ DimClass make_dim(int transposed, int r, int k, int s
     d.Q = (O > r) ? (O - r + s - 1) / s : 0;
   }
   d.fq = dev_fastdiv((uint32_t)d.Q);
-  return d;
-}
-
-static DimClass make_dim_host(int transposed, int r, int k, int s, int p, int O) {
-  DimClass d;
-  if (!transposed) {
-    d.nk = k; d.k0 = 0; d.ks = 1; d.c0 = -p; d.cs = 1; d.a = s; d.so = 1; d.r = 0; d.Q = O;
-  } else {
-    d.k0 = (r + p) % s;
-    d.nk = (d.k0 < k) ? (k - d.k0 + s - 1) / s : 0;
-    d.ks = s;
-    d.c0 = (r + p - d.k0) / s;
-    d.cs = -1;
-    d.a = 1;
-    d.so = s;
-    d.r = r;
-    d.Q = (O > r) ? (O - r + s - 1) / s : 0;
-  }
-  d.fq = make_fastdiv((uint32_t)d.Q);
   return d;
 }
 
@@ -406,29 +375,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     return;
   }
 
-  // ---- epilogue: bias, statistics, activation, channels-last store --------------------------------------
-  // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time; the activation is
-  // dispatched ONCE around the loops: a per-value switch is replicated, branches included, in every unrolled copy)
-  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  const bool want_stats = p.stats != nullptr;
-  // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
-  // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
-  // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
-  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
-  constexpr int RING_BYTES = STAGES * STAGE_BYTES + DUMP_BYTES;
-  // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
-  constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
-                     : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
-  constexpr bool VIA_LDS = sizeof(T) == 2 && TILE_C >= 64 && NH > 0;
-  constexpr int HALF_P = VIA_LDS ? TILE_P / NH : TILE_P;
-  constexpr int OUT_BYTES = VIA_LDS ? HALF_P * TILE_C * 2 : 0;
-  static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= STAGES * STAGE_BYTES + 1024, "epilogue LDS exceeds the staging ring");
-  // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
-  // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
-  // same 2*Cout addresses; bn_from_sums folds the replicas).
-  float* red = reinterpret_cast<float*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
-  long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
-  auto out_offset = [&](long long m) -> long long {
+  // ---- epilogue: bias, statistics, activation, channels-last store (conv_epilogue.hpp) ----------------------
+  EpiP e;
+  e.y = p.y; e.bias = p.bias; e.stats = p.stats; e.Cop = p.Cop; e.Cout = p.Cout; e.act = p.act; e.slope = p.slope;
+  e.mul_src = p.mul_src; e.mul_act = p.mul_act; e.mul_slope = p.mul_slope;
+  auto out_offset = [&](int r) -> long long {       // tile row -> element offset of the output pixel, or -1
+    const long long m = m0 + r;
     if (m >= Mcls) return -1;
     uint32_t q = (uint32_t)m, qw, qh, qd;
     fdivmod(q, dw.fq, q, qw);
@@ -437,160 +389,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     const int n = (int)q;
     return ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
   };
-  long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
-  bool pvalid[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
-    pvalid[j] = m < Mcls;
-    if constexpr (!VIA_LDS) opix[j] = out_offset(m);
-  }
-  if (VIA_LDS || want_stats) __syncthreads();      // every wave is done reading the last stage
-  if constexpr (VIA_LDS) {
-    for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(m0 + r);
-  }
-  // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
-  // accumulator tile across a store phase); the statistics of all sub-tiles are taken in pass 0
-  auto body = [&](auto actf, auto hc) {
-    constexpr int H = decltype(hc)::value;
-    constexpr int JN = VIA_LDS ? NJ / NH : NJ;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c = n0 + wave_c0 + i * 16 + cq;
-      float b4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
-      }
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const bool emit = j >= H * JN && j < (H + 1) * JN;     // compile-time after unrolling
-        if (!emit && H != 0) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = acc[i][j][r] + b4[r];
-          if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
-          v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
-        }
-        if (!emit) continue;
-        if constexpr (VIA_LDS) {
-          // 8-byte unit u of tile row (pixel) with row & 15 == n sits at slot u ^ n: the 16 rows of one ds_write_b64
-          // group land on 16 different bank pairs, and a pixel's 16-byte chunk c is found whole at c ^ (n >> 1)
-          const int n = lane & 15;
-          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(smem + ((wave / WAVES_C) * (JN * 16) + (j - H * JN) * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
-        } else {
-          if (opix[j] >= 0 && c < p.Cop) {
-            T* dst = yg + opix[j] + c;
-            if (p.mul_src != nullptr) {
-              const T* ms = reinterpret_cast<const T*>(p.mul_src) + opix[j] + c;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(Elem<T>::ld(ms + r), p.mul_act, p.mul_slope);
-            }
-            if constexpr (sizeof(T) == 2) {
-              uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-              *reinterpret_cast<uint2*>(dst) = o;
-            } else {
-              *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-          }
-        }
-      }
-      if (H == 0 && want_stats) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float a = s1[r], b = s2[r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-          if ((lane & 15) == 0) {
-            const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
-            red[cl * WAVES_P + (wave / WAVES_C)] = a;
-            red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
-          }
-        }
-      }
-    }
-  };
-  // store phase of pass h: the rows of pixel half h leave LDS as whole pixel rows, 16 bytes per lane
-  auto store_rows = [&](int h) {
-    constexpr int CPRW = TILE_C / 8;          // 16-byte chunks per tile row
-    constexpr int RPW = 64 / CPRW;            // tile rows per wave-instruction
-    constexpr int NIT = HALF_P / RPW;         // wave-instructions per pass
-    constexpr int U = NH == 1 ? 4 : 2;        // rows in flight per lane (two passes: half the waves still hold their tile)
-    const int c = lane % CPRW;
-    const bool cok = n0 + c * 8 < p.Cop;
-    const bf16_t* ms = reinterpret_cast<const bf16_t*>(p.mul_src);
-    for (int it0 = wave; it0 < NIT; it0 += U * NWAVES) {
-      long long off[U];
-      uint4 v[U], mv[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int it = it0 + u * NWAVES;
-        const int lr = it * RPW + lane / CPRW;               // row of this pass's LDS image = (pixel wave, sub-tile, pixel)
-        const int tr = (lr / (HALF_P / WAVES_P)) * (TILE_P / WAVES_P) + h * (HALF_P / WAVES_P) + lr % (HALF_P / WAVES_P);
-        off[u] = (it < NIT && cok) ? orow[tr] : -1;
-      }
-      if (ms != nullptr) {      // the producer's activation output at the same positions: all U loads issued together
-#pragma unroll
-        for (int u = 0; u < U; ++u) mv[u] = *reinterpret_cast<const uint4*>(ms + (off[u] >= 0 ? off[u] + n0 + c * 8 : 0));
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int it = it0 + u * NWAVES;
-        const int row = (it < NIT ? it : wave % NIT) * RPW + lane / CPRW, n = row & 15;
-        v[u] = *reinterpret_cast<const uint4*>(smem + row * (TILE_C * 2) + ((c ^ (n >> 1)) << 4));
-        if (n & 1) v[u] = make_uint4(v[u].z, v[u].w, v[u].x, v[u].y);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (ms != nullptr) {
-          float f[8], m[8];
-          load8(reinterpret_cast<const bf16_t*>(&v[u]), f);
-          load8(reinterpret_cast<const bf16_t*>(&mv[u]), m);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul_act, p.mul_slope);
-          store8(reinterpret_cast<bf16_t*>(&v[u]), f);
-        }
-        if (off[u] >= 0) *reinterpret_cast<uint4*>(yg + off[u] + n0 + c * 8) = v[u];
-      }
-    }
-  };
-  auto dispatch_body = [&](auto hc) {
-    const float slope = p.slope;
-    constexpr bool FAST = sizeof(T) == 2;     // bf16 output: v_exp/v_rcp forms are exact to far below half an ulp
-    switch (p.act) {
-      case VFD_ACT_LRELU: body([slope](float t) { return t > 0.f ? t : t * slope; }, hc); break;
-      case VFD_ACT_SIGMOID: body([](float t) { return FAST ? fast_sigmoid(t) : 1.f / (1.f + __expf(-t)); }, hc); break;
-      case VFD_ACT_TANH: body([](float t) { return FAST ? fast_tanh(t) : tanhf(t); }, hc); break;
-      default: body([](float t) { return t; }, hc); break;
-    }
-  };
-  dispatch_body(std::integral_constant<int, 0>());
-  if constexpr (!VIA_LDS) {
-    if (want_stats) __syncthreads();
-  } else {
-    __syncthreads();
-    store_rows(0);
-    if constexpr (NH == 2) {
-      __syncthreads();
-      dispatch_body(std::integral_constant<int, 1>());
-      __syncthreads();
-      store_rows(1);
-    }
-  }
-  if (want_stats) {
-    float* rep = p.stats + (size_t)((ptile + cls_id) % VFD_STATS_REPLICAS) * 2 * p.Cop;
-    for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
-      const int which = t / TILE_C, cl = t - which * TILE_C;
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
-      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);
-    }
-  }
+  conv_epilogue<T, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES>(smem, acc, e, n0, ptile + cls_id, out_offset,
+                                                                                [&](int r) { return m0 + r < Mcls; });
 }
 
 // y[m][c] = act(sum_ks ws[ks][m][c] + bias[c]) for the split-K path (regular convolutions only: out pixel == m)
@@ -748,6 +548,14 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
       return VFD_OK;
     }
   }
+  {
+    const int h = vfd_conv_halo_try(d, x, packed, bias, y, stats, mul_src, mul_act, mul_slope, ws_query != nullptr, as_stream(stream));
+    if (h < 0) return VFD_ELAUNCH;
+    if (h > 0) {
+      if (ws_query != nullptr) *ws_query = 0;
+      return VFD_OK;
+    }
+  }
   ConvP p;
   p.x = x; p.w = packed; p.y = y; p.bias = bias; p.stats = stats;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = cpad(d->Cin);
@@ -798,6 +606,10 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
   const char* t = dn.dtype == VFD_BF16 ? "bf16" : "f32";
   if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0, true, nullptr) > 0) {
     snprintf(buf, n, "%s<%s>", dn.transposed ? "convt_thin" : "conv_cin8", t);
+    return VFD_OK;
+  }
+  if (vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, true, nullptr) > 0) {
+    snprintf(buf, n, "conv_halo<%s,%s>", t, dn.Cout > 32 ? "64c_x_256p" : "32c_x_256p");
     return VFD_OK;
   }
   const int c = dn.Cout;   // launch<T>() below
