@@ -138,6 +138,13 @@ int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes);
 int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
                    void* stream);
 int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream);
+/* Dispatch switch of the halo-tiled filter-gradient kernel (conv_wgrad_halo.hip: stride-1 layers with a 3 x 3 in-plane
+ * footprint, kd 1 or 3, >= 33 channels on both sides, bf16): 0 = default rules, 1 = never (conv_wgrad's per-tap
+ * gather), 2 = whenever eligible (tests).  Returns the previous mode.  vfd_wgrad_workspace / vfd_conv_wgrad /
+ * vfd_wgrad_reduce of one layer must see the same mode. */
+int vfd_wgrad_set_halo_mode(int mode);
+/* Name of the kernel vfd_conv_wgrad() dispatches this layer to ("conv_wgrad<bf16,64x256>", "conv_wgrad_halo<bf16>"). */
+int vfd_wgrad_kernel_name(const vfd_conv_desc* d, char* buf, size_t n);
 size_t vfd_bias_grad_workspace(int C);
 int vfd_bias_grad(int dtype, const void* dy, float* db, int64_t rows, int C, float beta, void* ws, void* stream);
 

@@ -35,7 +35,7 @@ CASES = [
 ]
 
 
-def _run(case, halo_mode, dev, act=0, slope=0.0, stats=False):
+def _run(case, halo_mode, dev, act=0, slope=0.0, stats=False, wg_mode=1):
     from vfd_gan_amd import _lib, functional as F
     name, xs, cout, k, s, p, op, tr, has_bias = case
     nd = len(xs) - 2
@@ -46,6 +46,7 @@ def _run(case, halo_mode, dev, act=0, slope=0.0, stats=False):
     b = _rand((cout,), 3, 0.5) if has_bias else None
     lib = _lib.load()
     prev = lib.vfd_conv_set_halo_mode(halo_mode)
+    prev_wg = lib.vfd_wgrad_set_halo_mode(wg_mode)
     try:
         xd = x.to(dev).requires_grad_()
         wd = torch.nn.Parameter(w.to(dev))
@@ -66,6 +67,7 @@ def _run(case, halo_mode, dev, act=0, slope=0.0, stats=False):
                     gb=bd.grad.cpu() if has_bias else None, sums=sums.cpu() if stats else None, name=names, x=x, w=w, b=b, gy=gy)
     finally:
         lib.vfd_conv_set_halo_mode(prev)
+        lib.vfd_wgrad_set_halo_mode(prev_wg)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
@@ -138,3 +140,49 @@ def test_halo_activation_gradient_handover(dev):
     assert relerr(xd.grad, xr.grad) < 3e-2, relerr(xd.grad, xr.grad)
     for (k, pm), (_, pr) in zip(mine.named_parameters(), ref.named_parameters()):
         assert relerr(pm.grad, pr.grad) < 3e-2, (k, relerr(pm.grad, pr.grad))
+
+
+WG_CASES = [
+    # stride-1, 3 x 3 in-plane footprint, >= 33 channels on both sides: conv_wgrad_halo.hip
+    ("c3d_k3_64to64", (2, 64, 6, 9, 20), 64, 3, 1, 1, 0, False, True),            # partial blocks in h and w, 3 depth taps
+    ("c3d_k3_40to50", (1, 40, 5, 16, 16), 50, 3, 1, 1, 0, False, False),          # partial channel tiles on both sides
+    ("c3d_k3_96to72", (1, 96, 3, 8, 32), 72, 3, 1, 1, 0, False, True),            # 2 x 2 channel tiles
+    ("c3d_k133_86to96", (1, 86, 4, 11, 17), 96, (1, 3, 3), 1, (0, 1, 1), 0, False, True),   # one depth tap
+    ("c2d_k3_64to48", (3, 64, 20, 24), 48, 3, 1, 1, 0, False, True),              # frames (D = 1)
+    ("t3d_k3s1_128to64", (1, 128, 4, 8, 16), 64, 3, 1, 1, 0, True, True),         # transposed: (S, G) = (x, dy)
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_halo_filter_gradient(case, dev):
+    """conv_wgrad_halo against the torch CPU filter gradient on the same bf16-rounded operands and against conv_wgrad's
+    per-tap gather on identical device inputs (float32 slabs of the same bf16 products in another order: 1e-5)."""
+    from vfd_gan_amd import _lib, functional as F
+    import ctypes
+    name, xs, cout, k, s, p, op, tr, has_bias = case
+    nd = len(xs) - 2
+    h = _run(case, 1, dev, wg_mode=2)
+    g = _run(case, 1, dev, wg_mode=1)
+    # the layer really is eligible: the workspace geometry differs between the two modes (one slab set per CU vs per tile round)
+    lib = _lib.load()
+    kk = (k,) * nd if isinstance(k, int) else k
+    xc = F.to_cl(h["x"].to(dev), torch.bfloat16)
+    out_dhw = tuple(h["raw"].shape[1:4])
+    desc = F._make_desc(xs[0], tuple(xc.t.shape[1:4]), xs[1], out_dhw, cout, F._triple(kk, nd, 1), F._triple(s, nd, 1), F._triple(p, nd, 0),
+                        tr, torch.bfloat16)
+    names = []
+    for mode in (2, 1):
+        prev = lib.vfd_wgrad_set_halo_mode(mode)
+        try:
+            buf = ctypes.create_string_buffer(64)
+            _lib.check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64))
+            names.append(buf.value.decode())
+        finally:
+            lib.vfd_wgrad_set_halo_mode(prev)
+    assert names[0] == "conv_wgrad_halo<bf16>" and names[1].startswith("conv_wgrad<bf16"), names
+    xr, wr = h["x"].clone().requires_grad_(), h["w"].clone().requires_grad_()
+    fn = {(2, False): TF.conv2d, (3, False): TF.conv3d, (2, True): TF.conv_transpose2d, (3, True): TF.conv_transpose3d}[(nd, tr)]
+    yr = fn(xr, wr, None, s, p, op) if tr else fn(xr, wr, None, s, p)
+    yr.backward(h["gy"])
+    assert relerr(h["gw"], wr.grad) < TOL[torch.bfloat16], ("wgrad", relerr(h["gw"], wr.grad))
+    assert relerr(h["gw"], g["gw"]) < 1e-5, ("wgrad vs conv_wgrad", relerr(h["gw"], g["gw"]))

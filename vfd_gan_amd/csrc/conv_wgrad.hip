@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgGeom {
+  bool halo;      // conv_wgrad_halo.hip takes this layer (nsplit / bytes are then its slab geometry)
   WgP p;
   int A, B, T, nsplit;
   int tr, tc;     // tile: S channels x flattened columns
@@ -320,6 +321,7 @@ struct WgGeom {
 int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   int rc = vfd_conv_check_desc(d);
   if (rc != VFD_OK) return rc;
+  g.halo = false;
   WgP& p = g.p;
   p.N = d->N;
   if (!d->transposed) {  // S = dy, G = x
@@ -360,10 +362,30 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   p.chunkM = chunk;
   g.nsplit = (int)nsplit;
   g.bytes = slab * (size_t)nsplit;
+  {
+    int hs = 0;
+    size_t hb = 0;
+    if (vfd_wgrad_halo_geom(d, &hs, &hb, nullptr) > 0) {
+      g.halo = true;
+      g.nsplit = hs;
+      g.bytes = hb;
+    }
+  }
   return VFD_OK;
 }
 
 }  // namespace
+
+extern "C" int vfd_wgrad_kernel_name(const vfd_conv_desc* d, char* buf, size_t n) {
+  VFD_REQUIRE(buf != nullptr && n > 0, "wgrad_kernel_name: bad arguments");
+  WgGeom g;
+  int rc = make_geom(d, g);
+  if (rc != VFD_OK) return rc;
+  const char* t = d->dtype == VFD_BF16 ? "bf16" : "f32";
+  if (g.halo) snprintf(buf, n, "conv_wgrad_halo<%s>", t);
+  else snprintf(buf, n, "conv_wgrad<%s,%dx%d>", t, g.tr, g.tc);
+  return VFD_OK;
+}
 
 extern "C" int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes) {
   WgGeom g;
@@ -381,6 +403,13 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   if (rc != VFD_OK) return rc;
   VFD_REQUIRE(x && dy && ws, "wgrad: null pointer");
   if (ws_bytes < g.bytes) { vfd_set_error("wgrad: workspace %zu < %zu bytes", ws_bytes, g.bytes); return VFD_ENOSPACE; }
+  if (g.halo) {
+    const int h = vfd_wgrad_halo_launch(d, x, dy, ws, as_stream(stream));
+    if (h < 0) { vfd_set_error("conv_wgrad_halo: launch failed"); return VFD_ELAUNCH; }
+    if (h > 0) return VFD_OK;
+    vfd_set_error("conv_wgrad_halo: geometry changed between the workspace query and the launch");
+    return VFD_EINVAL;
+  }
   g.p.S = d->transposed ? x : dy;
   g.p.G = d->transposed ? dy : x;
   g.p.ws = reinterpret_cast<float*>(ws);

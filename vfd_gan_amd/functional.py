@@ -444,8 +444,9 @@ class _Conv(torch.autograd.Function):
                   "conv_wgrad")
             if timer is not None:
                 e1.record()
-                timer.records.append(("conv_wgrad<%s>" % ("bf16" if dt == torch.bfloat16 else "f32"), _conv_flops(desc), e0, e1,
-                                      _geom_str(desc)))
+                buf = ctypes.create_string_buffer(64)
+                check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64), "wgrad_kernel_name")
+                timer.records.append((buf.value.decode(), _conv_flops(desc), e0, e1, _geom_str(desc)))
             direct = _direct_grad(weight)
             if direct is not None:
                 check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
