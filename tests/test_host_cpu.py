@@ -253,7 +253,7 @@ def test_ring_kernels_isa_audit():
     rings = 0
     bad = {}
     with tempfile.TemporaryDirectory() as td:
-        for src in ("conv_igemm.hip", "conv_halo.hip", "conv_wgrad.hip", "conv_small.hip"):
+        for src in ("conv_igemm.hip", "conv_halo.hip", "conv_wgrad.hip", "conv_wgrad_halo.hip", "conv_small.hip"):
             for r in isa_audit.audit_file(os.path.join(isa_audit.CSRC, src), td):
                 rings += sum(1 for lp in r["loops"] if lp["dma"])
                 if r["violations"]:

@@ -12,14 +12,19 @@
 // (TD+kd-1) x (TH+kh-1) x (16+kw-1) pixels and reads the B fragments of every tap from it at shifted rows: the
 // im2col happens in the LDS addressing.  Only the [TILE_C][32] filter slice of a tap streams through a 2-deep ring.
 //
-//   LDS      halo rows of 64 B (one pixel's 32-channel chunk), 16-byte slot c of row r stored at c ^ 2*((r>>2)&1):
-//            conflict-free for ds_read_b128 fragments of 16 consecutive rows at ANY row alignment (the tap shifts
-//            move the fragment's first row arbitrarily; checked against the lane groups of MI355X_MICROARCH.md §LDS);
-//            filter stage [TILE_C rows][64 B], same swizzle.
-//   waves    4 per workgroup, each 64 pixels (4 groups of 16 consecutive w) x TILE_C channels, 3 workgroups per CU
-//            (49.7 KB LDS): while one loads its next halo block the others compute.
-//   sync     one raw s_barrier per tap, `s_waitcnt vmcnt(0)` (every DMA issued one tap earlier) — no counted waits:
-//            a halo block takes a varying number of DMA instructions per wave.
+//   LDS      halo rows of 64 B (one pixel's 32-channel chunk) stored W-MAJOR: row = wx * S + (dz * HH + hy) with the pitch
+//            S = HD*HH rounded up to 1 (mod 4), 16-byte slot c of a row at c ^ 2*((wx>>2)&1).  A B fragment (16
+//            consecutive w at fixed (d,h)) then touches rows S apart: bank quarter (r & 3) advances by 1 per pixel, the
+//            swizzle depends on wx only, and the fragment is conflict-free for ds_read_b128 at any tap shift (checked
+//            against the lane groups of MI355X_MICROARCH.md §LDS).  Above all the read address is
+//            [lane constant for the w shift] + [wave-uniform (d,h) shift]: ONE vector add per fragment and stage.  (The
+//            first version kept h*w-major rows and recomputed a row-dependent swizzle per tap: ~60 VALU per 16 MFMAs and
+//            wave; an ablation showed the kernel's time did not change with the MFMAs removed — it was issue-bound.)
+//            filter stage [taps of one (kd,kh)][TILE_C rows][64 B], rows 16-aligned, slot c of row r at c ^ 2*((r>>2)&1).
+//   waves    4 per workgroup, each 64 pixels (4 groups of 16 consecutive w) x TILE_C channels, 2 workgroups per CU
+//            (67.6 KB LDS): while one loads its next halo block the other computes.
+//   sync     one raw s_barrier per (kd,kh) filter stage = up to 3 taps = 48 MFMAs per wave; `s_waitcnt vmcnt(0)` (every
+//            DMA issued one stage earlier) — no counted waits: a halo block takes a varying number of DMA instructions.
 #include "common.hpp"
 #include "conv_epilogue.hpp"
 #include <stdlib.h>
@@ -46,21 +51,29 @@ struct HaloP {
 
 __device__ uint4 g_halo_zero_page[4];
 
+constexpr int halo_pitch(int hdhh) { return hdhh + ((1 - hdhh) % 4 + 4) % 4; }    // >= hdhh, == 1 (mod 4)
+
 template <int TILE_C, int TD, int TH>
 struct HaloCfg {
   static constexpr int NI = TILE_C / 16;
   static constexpr int NJ = 4;
   static constexpr int HD_MAX = TD > 1 ? TD + 2 : 1;          // frames (TD == 1) carry no depth halo
-  static constexpr int ROWS_MAX = HD_MAX * (TH + 2) * 18;
+  static constexpr int S_MAX = halo_pitch(HD_MAX * (TH + 2));
+  static constexpr int ROWS_MAX = 18 * S_MAX;
   static constexpr int HALO_BYTES = (ROWS_MAX + 15) / 16 * 1024;
-  static constexpr int FSTAGE = TILE_C * 64;
+  static constexpr int FTAP = TILE_C * 64;                    // one tap's filter slice
+  static constexpr int FSTAGE = 3 * FTAP;                     // the (up to 3) w-taps of one (kd, kh)
   static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 4 + 256 * 8;
-  static constexpr int LDS = (HALO_BYTES + 2 * FSTAGE > EPI_BYTES) ? HALO_BYTES + 2 * FSTAGE : EPI_BYTES;
+  static constexpr int NFS = 2;                               // filter ring depth
+  static constexpr int LDS = (HALO_BYTES + NFS * FSTAGE > EPI_BYTES) ? HALO_BYTES + NFS * FSTAGE : EPI_BYTES;
   static constexpr int NHW = ((ROWS_MAX + 15) / 16 + 3) / 4;  // halo DMA instructions per wave (upper bound)
+  static constexpr int NFW = (3 * NI + 3) / 4;                // filter DMA instructions per wave and stage (upper bound)
 };
 
-template <int TILE_C, int TD, int TH>
-__global__ __launch_bounds__(256, 3) void conv_halo_kernel(const HaloP p) {
+// DBG (tuning builds only, env VFD_HALO_DBG; results are WRONG): 1 = no LDS-DMA inside the loop, 2 = no barrier inside the
+// loop, 4 = no MFMA, 8 = no main loop (prologue + epilogue only), 16 = no fragment reads
+template <int TILE_C, int TD, int TH, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
   using C = HaloCfg<TILE_C, TD, TH>;
   constexpr int NI = C::NI, NJ = C::NJ;
   static_assert(TD * TH == 16, "a tile is 16 groups of 16 pixels");
@@ -92,76 +105,84 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const HaloP p) {
   const int q0d = (int)itd * TD, q0h = (int)ith * TH, q0w = (int)itw * 16;
   if (q0d >= dd.Q || q0h >= dh.Q || q0w >= dw.Q) return;      // smaller classes have fewer tiles (uniform per workgroup)
   const int n0 = ytile * TILE_C;
-  const int ntaps = dd.nk * dh.nk * dw.nk;
   const int nchunks = (p.Cip + 31) >> 5;
-  const int nsteps = ntaps * nchunks;
 
   // halo block of this tile: input coordinates [o, o + H) per dimension
   const int HD = TD + dd.nk - 1, HH = TH + dh.nk - 1, HW = 16 + dw.nk - 1;
   const int od0 = q0d + dd.c0 - (dd.cs < 0 ? dd.nk - 1 : 0);
   const int oh0 = q0h + dh.c0 - (dh.cs < 0 ? dh.nk - 1 : 0);
   const int ow0 = q0w + dw.c0 - (dw.cs < 0 ? dw.nk - 1 : 0);
-  const int rows = HD * HH * HW;
+  const int HDH = HD * HH;
+  const int S = HDH + ((1 - HDH) % 4 + 4) % 4;          // row pitch of one w column (1 mod 4)
+  const int rows = HW * S;
   const int ninst = (rows + 15) >> 4;
+  const int nstages = dd.nk * dh.nk * nchunks;           // one filter stage per (chunk, kd, kh)
 
   constexpr uint32_t NONE = 0xffffffffu;
   const int slot = lane & 3;
-  // ---- per-lane filter row (this wave's DMA instruction = 16 rows of the stage): granule offset of (row, tap 0, ch 0)
-  uint32_t wrow = NONE;
-  {
-    const int row = wave * 16 + (lane >> 2);
-    const int co = n0 + row;
-    if (wave < NI && co < p.e.Cout) wrow = (uint32_t)(((long long)co * p.Kw) >> 3);
-  }
-  // source-side swizzle: physical slot s of LDS row r holds logical chunk s ^ 2*((r>>2)&1); every DMA instruction starts
-  // at a multiple of 16 rows, so the row's bit 2 is bit 4 of the lane
-  const int lchunk = slot ^ (((lane >> 4) & 1) << 1);
   const uint32_t smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const uint32_t halo_base = smem_base, filt_base = smem_base + C::HALO_BYTES;
   const char* zero = reinterpret_cast<const char*>(g_halo_zero_page);
   const char* xg = reinterpret_cast<const char*>(p.x);
   const char* wg = reinterpret_cast<const char*>(p.w);
 
-  // ---- per-lane halo sources (16-byte granule offsets of the pixel's channel 0, or NONE): once per tile
+  // ---- per-lane halo sources, once per tile: granule offset of the pixel's channel 0 (or NONE) and the 16-byte piece of
+  // the 32-channel chunk this lane fetches (source-side swizzle: physical slot s of a row of column wx holds logical
+  // chunk s ^ 2*((wx>>2)&1))
   uint32_t hoff[C::NHW];
+  int hlc[C::NHW];
   {
-    const float inv_hw = 1.0f / (float)(HH * HW), inv_w = 1.0f / (float)HW;
+    const float inv_s = 1.0f / (float)S, inv_hh = 1.0f / (float)HH;
     const int gpp = p.Cip >> 3;   // granules per pixel
 #pragma unroll
     for (int k = 0; k < C::NHW; ++k) {
       const int r = (wave + 4 * k) * 16 + (lane >> 2);
+      const int wx = (int)(((float)r + 0.5f) * inv_s);
+      const int rem = r - wx * S;
+      const int dz = (int)(((float)rem + 0.5f) * inv_hh);
+      const int hy = rem - dz * HH;
+      const int id = od0 + dz, ih = oh0 + hy, iw = ow0 + wx;
       uint32_t off = NONE;
-      if (r < rows) {
-        const int dz = (int)(((float)r + 0.5f) * inv_hw);
-        const int rem = r - dz * HH * HW;
-        const int hy = (int)(((float)rem + 0.5f) * inv_w);
-        const int wx = rem - hy * HW;
-        const int id = od0 + dz, ih = oh0 + hy, iw = ow0 + wx;
-        if ((unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-          off = (uint32_t)(((n * p.Di + id) * p.Hi + ih) * p.Wi + iw) * (uint32_t)gpp;
-      }
+      if (r < rows && rem < HDH && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+        off = (uint32_t)(((n * p.Di + id) * p.Hi + ih) * p.Wi + iw) * (uint32_t)gpp;
       hoff[k] = off;
+      hlc[k] = slot ^ (((wx >> 2) & 1) << 1);
     }
   }
   auto issue_halo = [&](int chunk) __attribute__((always_inline)) {
-    const int ch = chunk * 32 + lchunk * 8;
-    const bool chok = ch < p.Cip;
 #pragma unroll
     for (int k = 0; k < C::NHW; ++k) {
       const int inst = wave + 4 * k;       // wave-uniform
       if (inst < ninst) {
-        const char* src = (chok && hoff[k] != NONE) ? xg + ((size_t)hoff[k] << 4) + ch * 2 : zero;
+        const int ch = chunk * 32 + hlc[k] * 8;
+        const char* src = (ch < p.Cip && hoff[k] != NONE) ? xg + ((size_t)hoff[k] << 4) + ch * 2 : zero;
         dma16_to_lds(src, halo_base + inst * 1024);
       }
     }
   };
-  // filter slice of tap (td, th, tw), channel chunk `chunk` -> stage fs
-  auto issue_filter = [&](int fs, int td, int th, int tw, int chunk) __attribute__((always_inline)) {
-    if (wave < NI) {
-      const int tapidx = ((dd.k0 + td * dd.ks) * p.kh + (dh.k0 + th * dh.ks)) * p.kw + (dw.k0 + tw * dw.ks);
-      const int ch = chunk * 32 + lchunk * 8;
-      const char* src = (wrow != NONE && ch < p.Cip) ? wg + ((size_t)(wrow + (uint32_t)(tapidx * (p.Cip >> 3))) << 4) + ch * 2 : zero;
-      dma16_to_lds(src, filt_base + fs * C::FSTAGE + wave * 1024);
+  // ---- filter stage of (kd tap td, kh tap th, chunk): slices of the w-taps tw = 0 .. nkw-1, [tw][TILE_C rows][64 B];
+  // DMA instruction `inst` of the stage = 16 rows: tap inst / NI, row block inst % NI; wave w issues inst = w, w+4, ...
+  uint32_t wrow[C::NFW];         // granule offset of (row, tap 0, channel 0) for this lane's row of instruction k, or NONE
+  int wtap[C::NFW];
+#pragma unroll
+  for (int k = 0; k < C::NFW; ++k) {
+    const int inst = wave + 4 * k;
+    const int co = n0 + (inst % NI) * 16 + (lane >> 2);
+    wtap[k] = inst / NI;
+    wrow[k] = (co < p.e.Cout) ? (uint32_t)(((long long)co * p.Kw) >> 3) : NONE;
+  }
+  const int flc = slot ^ (((lane >> 4) & 1) << 1);       // rows of a 16-row instruction: bit 2 of the row = bit 4 of the lane
+  auto issue_filter = [&](int fs, int td, int th, int chunk) __attribute__((always_inline)) {
+    const int tap0 = ((dd.k0 + td * dd.ks) * p.kh + (dh.k0 + th * dh.ks)) * p.kw + dw.k0;
+    const int ch = chunk * 32 + flc * 8;
+#pragma unroll
+    for (int k = 0; k < C::NFW; ++k) {
+      const int inst = wave + 4 * k;
+      if (inst < dw.nk * NI) {
+        const int tapidx = tap0 + wtap[k] * dw.ks;
+        const char* src = (wrow[k] != NONE && ch < p.Cip) ? wg + ((size_t)(wrow[k] + (uint32_t)(tapidx * (p.Cip >> 3))) << 4) + ch * 2 : zero;
+        dma16_to_lds(src, filt_base + fs * C::FSTAGE + inst * 1024);
+      }
     }
   };
 
@@ -169,12 +190,18 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const HaloP p) {
   const int l15 = lane & 15, c16 = (lane >> 4) << 4;
   // A (filter stage): row = 16 i + l15, rows start at multiples of 16: swizzle bit = bit 2 of l15
   const int a_off = (l15 << 6) + (c16 ^ ((l15 & 4) << 3));
-  // B (halo): first row of pixel group j of this wave at tap shift 0
-  int brow[NJ];
+  // B (halo): pixel group j of this wave at w shift sw: row = (sw + l15) * S + (dl * HH + hl); the (kd,kh) shift of a stage
+  // adds a wave-uniform number of rows
+  int baddr[NJ][3];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int g = wave * 4 + j;
-    brow[j] = ((g / TH) * HH + (g % TH)) * HW + l15;
+    const int base = (g / TH) * HH + (g % TH);
+#pragma unroll
+    for (int sw = 0; sw < 3; ++sw) {
+      const int wx = sw + l15;
+      baddr[j][sw] = ((wx * S + base) << 6) + (c16 ^ (((wx >> 2) & 1) << 5));
+    }
   }
 
   f32x4 acc[NI][NJ];
@@ -183,50 +210,69 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(const HaloP p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- main loop: one tap of one channel chunk per iteration.
-  // (A variant that prefetched the next tap's fragments into a second register set and loaded the next halo block behind
-  // the last tap measured SLOWER: 804 vs 825 TFLOP/s on the 64->64 3-D layer, 377 vs 453 on the 2-D transposed pyramid
-  // layer — with three workgroups per CU a wave's LDS latency is already covered by the other workgroups' MFMAs, and the
-  // extra 40 registers and control flow cost more than the overlap gains.)
+  // ---- main loop: one filter stage = the w-taps of one (chunk, kd, kh) per iteration, 2-deep filter ring.
+  // Measured alternatives (tools/layer_bench.py --set anogan, 64->64 3-D layer forward / data gradient, TFLOP/s):
+  //   one tap per stage, h*w-major halo, per-tap swizzle arithmetic, 3 workgroups per CU      950 / 987
+  //   + next tap's fragments prefetched into a second register set                            804 / 825 (event-timed)
+  //   this version (w-major halo, 3-tap stages, 2 workgroups per CU)                          978 / 996
+  //   + 3-deep filter ring with a counted vmcnt (a slice issued two stages ahead)             941 / 959, and the 2-D
+  //     transposed pyramid layer 597 -> 443 (its LDS grows from 48 to 60 KB: 3 -> 2 workgroups per CU)
+  // An ablation (compile-time DBG variants) shows what is left: with the MFMAs removed the layer takes 1093 us, with the
+  // DMAs removed 1360, prologue + epilogue alone 390, against 1450..1690 for the whole: the phases of a workgroup
+  // (DMA wait -> barrier -> fragment reads -> MFMAs) run back to back and two workgroups per CU overlap them only partly.
+  auto next_pos = [&](int& a_td, int& a_th, int& a_chunk) __attribute__((always_inline)) {
+    if (++a_th == dh.nk) { a_th = 0; if (++a_td == dd.nk) { a_td = 0; ++a_chunk; } }
+  };
+  int td = 0, th = 0, chunk = 0;            // stage s
+  int td1 = 0, th1 = 0, chunk1 = 0;          // stage s+1 (the one to issue)
   issue_halo(0);
-  issue_filter(0, 0, 0, 0, 0);
-  int td = 0, th = 0, tw = 0, chunk = 0, fs = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    // next step's position
-    int ntw_ = tw + 1, nth_ = th, ntd_ = td, nchunk = chunk;
-    if (ntw_ == dw.nk) { ntw_ = 0; if (++nth_ == dh.nk) { nth_ = 0; if (++ntd_ == dd.nk) { ntd_ = 0; ++nchunk; } } }
-    const bool new_chunk = (td | th | tw) == 0 && chunk > 0;
-    // this step's filter slice (issued one step ago) and, in step 0, the first halo block have landed; every wave is done
-    // with the LDS reads of the previous step (the barrier waits for no counter: retire them explicitly)
+  issue_filter(0, 0, 0, 0);
+  next_pos(td1, th1, chunk1);
+  int fs = 0;
+  for (int s = 0; s < ((DBG & 8) ? 0 : nstages); ++s) {
+    const bool new_chunk = (td | th) == 0 && chunk > 0;
+    // this stage's filter slices (issued one stage ago) and, in stage 0, the first halo block have landed; every wave is
+    // done with the LDS reads of the previous stage (the barrier waits for no counter: retire them explicitly)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (new_chunk) issue_halo(chunk);                 // the old block is dead: all waves passed the barrier above
-    if (s + 1 < nsteps) issue_filter(fs ^ 1, ntd_, nth_, ntw_, nchunk);
+    if (new_chunk && !(DBG & 1)) issue_halo(chunk);                 // the old block is dead: all waves passed the barrier above
+    if (s + 1 < nstages && !(DBG & 1)) issue_filter(fs ^ 1, td1, th1, chunk1);
+    next_pos(td1, th1, chunk1);
     if (new_chunk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!(DBG & 2)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    {
-      const int sd_ = dd.cs > 0 ? td : dd.nk - 1 - td, sh_ = dh.cs > 0 ? th : dh.nk - 1 - th, sw_ = dw.cs > 0 ? tw : dw.nk - 1 - tw;
-      const int shift = (sd_ * HH + sh_) * HW + sw_;          // wave-uniform row shift of this tap
-      const char* ft = smem + C::HALO_BYTES + fs * C::FSTAGE;
-      bf16x8 a[NI], b[NJ];
+    const int sd_ = dd.cs > 0 ? td : dd.nk - 1 - td, sh_ = dh.cs > 0 ? th : dh.nk - 1 - th;
+    const int dh_off = (sd_ * HH + sh_) << 6;            // wave-uniform byte shift of this (kd, kh)
+    const char* ft = smem + C::HALO_BYTES + fs * C::FSTAGE;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ft + i * 1024 + a_off);
+    for (int sw = 0; sw < 3; ++sw) {
+      if (sw < dw.nk) {
+        const int tw = dw.cs > 0 ? sw : dw.nk - 1 - sw;   // filter tap whose input shift is sw
+        bf16x8 a[NI], b[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int v = brow[j] + shift;
-        b[j] = *reinterpret_cast<const bf16x8*>(smem + ((v << 6) + (c16 ^ ((v & 4) << 3))));
+        for (int i = 0; i < NI; ++i) {
+          if (DBG & 16) { asm volatile("" : "=v"(a[i]) : "v"(ft + tw * C::FTAP + a_off)); continue; }
+          a[i] = *reinterpret_cast<const bf16x8*>(ft + tw * C::FTAP + i * 1024 + a_off);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (DBG & 16) { asm volatile("" : "=v"(b[j]) : "v"(baddr[j][sw] + dh_off)); continue; }
+          b[j] = *reinterpret_cast<const bf16x8*>(smem + baddr[j][sw] + dh_off);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if (DBG & 4) { asm volatile("" :: "v"(a[i]), "v"(b[j])); continue; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          }
       }
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     fs ^= 1;
-    td = ntd_; th = nth_; tw = ntw_; chunk = nchunk;
+    next_pos(td, th, chunk);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -249,6 +295,23 @@ template <int TILE_C, int TD, int TH>
 int launch_halo(const HaloP& p, hipStream_t st) {
   const long long nwg = (long long)p.per_xcd * 8;
   if (nwg >= 0x7fffffffLL) return 0;
+#ifdef VFD_HALO_TUNING
+  static const int dbg = getenv("VFD_HALO_DBG") ? atoi(getenv("VFD_HALO_DBG")) : 0;
+  if (TILE_C == 64 && TD == 4) {
+    switch (dbg) {
+      case 1: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 1>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 2: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 2>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 4: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 4>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 5: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 5>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 7: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 7>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 8: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 8>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 16: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 16>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 20: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 20>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 23: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 23>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      default: break;
+    }
+  }
+#endif
   hipLaunchKernelGGL((conv_halo_kernel<TILE_C, TD, TH>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }

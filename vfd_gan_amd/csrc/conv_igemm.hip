@@ -337,8 +337,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       {
         constexpr int N = (NWT + NPT) * (STAGES - 2);
         static_assert(N < 64, "vmcnt field");
-        // s_waitcnt encoding (gfx9+): vmcnt = imm[3:0] | imm[15:14] << 4; expcnt imm[6:4] = 7, lgkmcnt imm[11:8] = 15: no wait
-        __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+        // hand-written wait (inline asm: tools/isa_audit.py tells it from a compiler-inserted one by the asm markers)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
       }
       // every wave's step-s DMAs landed AND every wave finished reading the stage the next issue overwrites: the
       // barrier itself waits for no counter, so this wave's LDS reads of the previous step are retired explicitly
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       Mma<T>::template step<NI, NJ, KSUB>(wt, pt, wave_c0, wave_p0, lane, acc);
       if (++stage == STAGES) stage = 0;
     }
-    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0): drain the trailing zero-page DMAs before LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing zero-page DMAs before LDS is released
   }
 
   const int cq = (lane >> 4) * 4;

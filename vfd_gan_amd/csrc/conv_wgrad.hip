@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
     for (int s = 0; s < nsteps; ++s) {
       {
         constexpr int N = (S_NT + G_NT) * (STAGES - 2);
-        __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));   // vmcnt(N)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");     // hand-written (asm): see tools/isa_audit.py
       }
       // WAR: the DMAs issued below overwrite the stage read in iteration s-1; `s_barrier` waits for no counter, so every
       // LDS read of that iteration must have RETURNED before this wave arrives here.  The compiler's own lgkmcnt waits
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
       WgMma<T>::template step<SROWB, GROWB>(st, st + S_BYTES, wr0, wc0, lane, acc);
       if (++stage == STAGES) stage = 0;
     }
-    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));   // vmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   // slab store: ws[z][r][col], D[row = r (lane>>4)*4+reg][col = lane&15]
