@@ -232,6 +232,7 @@ def main():
     ms = elapsed / a.steps * 1e3
 
     timer_steps = 0
+    event_overhead_us = 0.0
     if not a.no_kernel_timer:      # every rank takes part (the eager step issues the gradient collectives)
         # per-kernel pass, after the timed region: eager launches of the SAME step with HIP events around every MFMA
         # kernel.  Eager mode is host-bound (Python issues a launch every ~5 us), so a device-side delay of about one
@@ -252,12 +253,20 @@ def main():
         ticks_per_s = 20_000_000 / max(e0.elapsed_time(e1) * 1e-3, 1e-6)
         cyc = int(max(host_s, ms * 1e-3) * 1.3 * ticks_per_s)
         timer = F.KernelTimer()
+        empty = []          # event pairs with NOTHING between them, in the same queued state: the marker-to-marker latency
         for _ in range(timer_steps):
             torch.cuda._sleep(cyc)
+            for _ in range(16):
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+                eb.record()
+                empty.append((ea, eb))
             F.set_kernel_timer(timer)
             eager_step()
             F.set_kernel_timer(None)
             torch.cuda.synchronize()
+        ev = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in empty)
+        event_overhead_us = ev[len(ev) // 2]
     if world > 1:
         vdist.barrier()
 
@@ -299,19 +308,21 @@ def main():
                     print("%-34s %-66s x%-3d %8.1f us/launch %7.1f TF/s" % (name, geom, d["launches"] // timer_steps,
                           d["ms"] * 1e3 / d["launches"], d["flops"] / max(d["ms"], 1e-9) / 1e9), file=sys.stderr)
             name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic = None      # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-            for tname in ("r02_traffic_%s.json" % a.model, "r01_traffic.json"):        # runs folded by tools/pmc_traffic.py)
-                tpath = os.path.join(ROOT, "profiles", tname)
-                if a.dtype == "bf16" and os.path.exists(tpath):
-                    traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
-                    if traffic is not None or tname.startswith("r02"):
-                        break
+            # an event pair around a kernel also spans the second marker's own processing: the median EMPTY pair of the same
+            # pass is subtracted (rocprofv3's kernel-trace average of the graph replay is the cross-check, profiles/)
+            raw_us = d["ms"] * 1e3 / d["launches"]
+            net_us = max(raw_us - event_overhead_us, 0.5 * raw_us)
+            tf = d["flops"] / d["launches"] / (net_us * 1e-6) / 1e12
+            traffic = None      # HBM bytes per launch of this kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
+            tpath = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % a.model)       # WRITE_SIZE runs: tools/profile_all.sh)
+            if a.dtype == "bf16" and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": traffic,
                                "launches_per_step": d["launches"] // timer_steps,
                                "timed_in": "eager pass after the timed region, stream kept GPU-bound by a device-side delay",
-                               "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "avg_launch_us": round(net_us, 2), "avg_launch_us_raw_events": round(raw_us, 2),
+                               "event_pair_overhead_us": round(event_overhead_us, 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches_per_step": v["launches"] // timer_steps, "ms_per_step": round(v["ms"] / timer_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in sorted(summ.items())}

@@ -228,6 +228,16 @@ def mygan():
     OUT_JSON["mygan"] = rec
 
 
+def mygan224():
+    """BASELINE configs[3] geometry: the reference's size-agnostic U-Net NetG at 16x224x224 (B=1, dropout p=0, training-mode
+    BatchNorm).  Its NetD is locked to 16x128x128 (models/mygannet.py:134,176), so only the generator is pinned here."""
+    g = fill_module(RM.NetG(), 61).train()
+    set_dropout_p(g, 0.0)
+    with torch.no_grad():
+        out = g(seeded_tensor((1, 3, 16, 224, 224), 68))
+    OUT_JSON["mygan224"] = {"seeds": {"g": 61, "inp": 68}, "predict": summarize(out)}
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["kats", "args_defaults", "spatiotemp", "ganomaly", "anogan", "mygan"]
     jp, npz = os.path.join(HERE, "reference_vectors.json"), os.path.join(HERE, "reference_vectors.npz")

@@ -170,3 +170,14 @@ def test_mygan_step():
     assert R["netd112_raises"]
     d112 = OM.NetD(OM.make_args(16, 112))
     assert d112.spatdisc.linear.in_features == 1024 * 1 * 1
+
+
+def test_mygan_netg_224():
+    """BASELINE configs[3] geometry (16x224x224): the oracle's NetG against the reference's own NetG output (fixture
+    mygan224, generated by tests/golden/make_fixtures.py mygan224)."""
+    R = JS["mygan224"]
+    g = fill_module(OM.NetG(), R["seeds"]["g"]).train()
+    _set_p0(g)
+    with torch.no_grad():
+        out = g(seeded_tensor((1, 3, 16, 224, 224), R["seeds"]["inp"]))
+    check_summary(out, R["predict"], 1e-4, "predict@224")

@@ -257,7 +257,11 @@ def _packed_filter(weight, dt, transpose_ab, A, B, T):
     """Cached K-major copy of a filter parameter (see vfd_pack_filter)."""
     cache = weight.__dict__.setdefault("_vfd_packed", {})
     key = (dt, transpose_ab)
-    tag = (weight._version, _WEIGHT_EPOCH[0], weight.data_ptr())
+    # a parameter owned by vfd_gan_amd.optim.Adam also carries its optimiser's own epoch cell: the fused Adam kernel of
+    # ONE net then invalidates that net's packed copies only (the global epoch re-packed netD's filters after every
+    # netG update too: 42 pack launches per ganomaly step, about half of them for unchanged weights)
+    own = getattr(weight, "_vfd_epoch", None)
+    tag = (weight._version, _WEIGHT_EPOCH[0], own[0] if own is not None else 0, weight.data_ptr())
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]

@@ -57,6 +57,12 @@ class GraphedStep:
             program = m.step_program()
         else:
             program = [("graph", self._eager_step)]
+        # Packed filter copies are cached per parameter (functional._packed_filter).  A copy made BEFORE the capture and
+        # still valid at a net's first use inside it (AnoGAN: netD is re-packed at the end of step k, after its Adam update,
+        # and first used again at the start of step k+1) would be read by the captured kernels at its pre-capture address
+        # for ever — stale weights, and a dangling pointer once the cache replaces the tensor.  Invalidating every copy
+        # here makes each net's first use inside the capture produce its packs inside the graph.
+        F.invalidate_weight_cache()
         reducers = {id(r): r for kind, r in program if kind != "graph"}.values()
         for r in reducers:
             r.suspended = True         # no collective may be issued while a capture is open

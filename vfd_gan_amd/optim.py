@@ -33,6 +33,7 @@ class Adam(torch.optim.Optimizer):
             offs.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self._offsets, self._total = offs, total
+        self._epoch = [0]
         self.param_arena = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad_arena = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -45,6 +46,7 @@ class Adam(torch.optim.Optimizer):
                 p.data = view
                 p.grad = self.grad_arena[o:o + n].view(p.shape)
                 p._vfd_direct_grad = True    # backward kernels accumulate straight into the arena (functional._direct_grad)
+                p._vfd_epoch = self._epoch   # bumped by step(): invalidates THIS optimiser's packed filter copies only
         self._step = 0
         self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # device-side counter (graph replay)
         self._bc_dev = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -73,7 +75,7 @@ class Adam(torch.optim.Optimizer):
                                        self.exp_avg_sq.data_ptr(), self._total, float(g["lr"]), float(b1), float(b2),
                                        float(g["eps"]), self._step_dev.data_ptr(), self._bc_dev.data_ptr(),
                                        float(self.grad_scale), stream()), "adam_step_dev")
-        F.invalidate_weight_cache()
+        self._epoch[0] += 1          # the kernel wrote through raw pointers: no torch version bump
 
     # ---- resume support (the reference saves no optimiser state) -------------------------------
     def state_dict(self):
