@@ -48,6 +48,14 @@ CONV_CASES = [
     ("K6_convT2d_last_32to1", (2, 32, 6, 6), 1, 4, 2, 1, 0, True, False),
     ("K6_convT2d_last_128to4", (1, 128, 5, 9), 4, 4, 2, 1, 0, True, True),
     ("K6_convT2d_last_64to3_tall", (1, 64, 37, 5), 3, 4, 2, 1, 0, True, False),
+    # <= 8 input channels, any small filter (bf16: conv_cin8, round 2): 3-D k3 stems, the (1,3,3) / (3,1,1) / 1x1x1 factors of
+    # the (2+1)D stems, few output channels, and stride-1 transposed convolutions (= data gradients of <= 8-channel outputs)
+    ("K1_cin8_3d_k3_3to32", (2, 3, 6, 20, 20), 32, 3, 1, 1, 0, False, True),
+    ("K2_cin8_k133_3to14", (2, 3, 4, 24, 24), 14, (1, 3, 3), 1, (0, 1, 1), 0, False, True),
+    ("K3_cin8_k311_2to32", (1, 2, 8, 24, 24), 32, (3, 1, 1), 1, (1, 0, 0), 0, False, False),
+    ("K4_cin8_k111_3to2", (2, 3, 4, 24, 24), 2, 1, 1, 0, 0, False, True),
+    ("K5_cin8_T_k3s1_1to32", (1, 1, 6, 20, 20), 32, 3, 1, 1, 0, True, True),
+    ("K5_cin8_T_k311s1_2to21", (1, 2, 6, 12, 12), 21, (3, 1, 1), 1, (1, 0, 0), 0, True, False),
 ]
 
 
@@ -113,6 +121,27 @@ def test_conv_fused_act_and_stats(dt, dev):
         s2 = (pre * pre).sum(dim=(0, 2, 3, 4))
         folded = sums.view(F.STATS_REPLICAS, 2, 16).sum(0)
         assert relerr(folded[0, :13], s1) < 1e-4 and relerr(folded[1, :13], s2) < 1e-4
+
+
+def test_conv_cin8_stats_and_kernel_names(dev):
+    """conv_cin8 with BatchNorm sums in its epilogue (bf16): the 3-channel stems of anogan's NetD (Conv3d(3,32,3) + BN) and of
+    the (2+1)D blocks run on it; sums against the float32 convolution of the same bf16 operands; the dispatcher names it."""
+    from vfd_gan_amd import _lib, functional as F
+    for xs, cout, k, p in (((2, 3, 6, 20, 20), 32, (3, 3, 3), (1, 1, 1)), ((2, 3, 4, 24, 24), 14, (1, 3, 3), (0, 1, 1)),
+                           ((1, 2, 8, 24, 24), 32, (3, 1, 1), (1, 0, 0))):
+        x = _rand(xs, 21).bfloat16().float()
+        w = _rand((cout, xs[1]) + k, 22, 0.3).bfloat16().float()
+        b = _rand((cout,), 23)
+        pre = TF.conv3d(x, w, b, 1, p)
+        sums = F.new_stats_buffer(cout, dev)
+        xc = F.to_cl(x.to(dev), torch.bfloat16)
+        yc = F.conv(xc, torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)), 1, p, 0, False, _lib.ACT_LRELU, 0.2, stats=sums)
+        assert relerr(yc.to_torch(), TF.leaky_relu(pre, 0.2)) < TOL[torch.bfloat16]
+        cp = F.cpad(cout)
+        folded = sums.view(F.STATS_REPLICAS, 2, cp).sum(0)
+        assert relerr(folded[0, :cout], pre.sum(dim=(0, 2, 3, 4))) < 1e-4 and relerr(folded[1, :cout], (pre * pre).sum(dim=(0, 2, 3, 4))) < 1e-4
+        desc = F._make_desc(xs[0], tuple(xc.t.shape[1:4]), xs[1], tuple(yc.t.shape[1:4]), cout, k, (1, 1, 1), p, False, torch.bfloat16)
+        assert F._conv_kernel_name(desc, sums) == "conv_cin8<bf16>"
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])

@@ -34,7 +34,7 @@ void vfd_set_error(const char* fmt, ...);
   } while (0)
 
 // conv_small.hip: 1 = handled (or, with query, would be handled), 0 = not a thin-channel shape, < 0 = launch error
-int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, bool want_stats,
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
                        bool query, hipStream_t st);
 
 // conv_halo.hip: same return convention; unit-input-stride layers with <= 64 output channels (bf16)

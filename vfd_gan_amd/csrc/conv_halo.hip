@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
           if (DBG & 16) { asm volatile("" : "=v"(b[j]) : "v"(baddr[j][sw] + dh_off)); continue; }
           b[j] = *reinterpret_cast<const bf16x8*>(smem + baddr[j][sw] + dh_off);
         }
+        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
             if (DBG & 4) { asm volatile("" :: "v"(a[i]), "v"(b[j])); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
           }
+        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
       }
     }
     fs ^= 1;
@@ -308,6 +310,7 @@ int launch_halo(const HaloP& p, hipStream_t st) {
       case 16: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 16>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
       case 20: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 20>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
       case 23: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 23>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
+      case 32: hipLaunchKernelGGL((conv_halo_kernel<64, 4, 4, 32>), dim3((unsigned)nwg), dim3(256), 0, st, p); return 1;
       default: break;
     }
   }

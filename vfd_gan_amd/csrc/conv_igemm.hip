@@ -541,7 +541,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   }
   {
     // thin-channel pyramid ends have their own kernels (conv_small.hip); they need no workspace
-    const int h = mul_src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats != nullptr, ws_query != nullptr, as_stream(stream));
+    const int h = mul_src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
     if (h > 0) {
       if (ws_query != nullptr) *ws_query = 0;
@@ -604,8 +604,9 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
   int rc = vfd_conv_check_desc(&dn);
   if (rc != VFD_OK) return rc;
   const char* t = dn.dtype == VFD_BF16 ? "bf16" : "f32";
-  if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0, true, nullptr) > 0) {
-    snprintf(buf, n, "%s<%s>", dn.transposed ? "convt_thin" : "conv_cin8", t);
+  float dummy_stats;
+  if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0 ? &dummy_stats : nullptr, true, nullptr) > 0) {
+    snprintf(buf, n, "%s<%s>", cpad(dn.Cin) == 8 ? "conv_cin8" : "convt_thin", t);
     return VFD_OK;
   }
   if (vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, true, nullptr) > 0) {

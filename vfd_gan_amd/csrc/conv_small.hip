@@ -28,10 +28,12 @@ struct Cin8P {
   const bf16_t* w;      // packed [Cout][kd*kh*kw][8]
   bf16_t* y;
   const float* bias;
+  float* stats;         // BatchNorm partial sums [VFD_STATS_REPLICAS][2][Cop] (sum, sum of squares of conv + bias), or null
   int N, Di, Hi, Wi, Do, Ho, Wo, Cout, Cop;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int act;
   float slope;
+  int flip;             // 1: stride-1 transposed convolution = regular convolution with the taps reversed and pad k-1-p
   FastDiv fWo, fHo, fDo;
   long long M;          // output pixels
   int ntiles;           // tiles of CIN8_TILE pixels
@@ -42,27 +44,40 @@ constexpr int CIN8_NJ = 2;                 // 32 pixels per wave
 constexpr int CIN8_WAVES = 4;
 constexpr int CIN8_TILE = CIN8_WAVES * CIN8_NJ * 16;   // 128 pixels per workgroup and tile
 
-__global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin8P p) {
+// ROWS = kd*kh when the whole filter's activation fragments fit in registers (<= 9 rows: every load of a tile is issued
+// at once, and the NEXT tile's loads are issued before this tile's epilogue, so the load latency is paid behind the
+// epilogue instead of once per depth tap), 0 = generic (row group by row group; any kd, kh <= 4)
+// NIT = 16-channel blocks of the output a wave computes (1, 2 or 4): thin outputs (14, 21, 32 channels of the (2+1)D stems)
+// run a quarter / half of the MFMAs, filter-fragment reads and epilogue arithmetic of the 64-channel form
+template <int ROWS, int NIT>
+__global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_kernel(const Cin8P p) {
+  constexpr int NI_ = NIT;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // filter fragments [kd*4][NI][64 lanes][16 B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int g = lane >> 4;            // K group of the fragment = tap kx
-  const int nks = p.kd * 4;
+  const int nks = p.kd * p.kh;        // K-step = one filter row (kz, ky): its <= 4 taps x 8 channels
 
   // ---- filter -> LDS, in fragment order: lane (m = lane&15, g) of fragment (ks, i) holds w[i*16+m][ks*4+g][0..7]
-  for (int f = tid; f < nks * CIN8_NI * 64; f += 64 * CIN8_WAVES) {
-    const int l = f & 63, fi = (f >> 6) % CIN8_NI, ks = (f >> 6) / CIN8_NI;
-    // K-step ks = (kz, ky) with ky padded to 4 rows, K group = kx padded to 4 taps: absent taps are zero filter rows
-    const int co = fi * 16 + (l & 15), kz = ks >> 2, ky = ks & 3, kx = l >> 4;
+  for (int f = tid; f < nks * NI_ * 64; f += 64 * CIN8_WAVES) {
+    const int l = f & 63, fi = (f >> 6) % NI_, ks = (f >> 6) / NI_;
+    // K-step ks = (kz, ky), K group = kx padded to 4 taps: absent taps are zero filter rows
+    const int co = fi * 16 + (l & 15), kz = ks / p.kh, ky = ks - kz * p.kh, kx = l >> 4;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (co < p.Cout && ky < p.kh && kx < p.kw)
-      v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (p.kd * p.kh * p.kw) + (kz * p.kh + ky) * p.kw + kx) * 8);
+    if (co < p.Cout && kx < p.kw) {
+      const int fz = p.flip ? p.kd - 1 - kz : kz, fy = p.flip ? p.kh - 1 - ky : ky, fx = p.flip ? p.kw - 1 - kx : kx;
+      v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (p.kd * p.kh * p.kw) + (fz * p.kh + fy) * p.kw + fx) * 8);
+    }
     *reinterpret_cast<uint4*>(smem + (size_t)f * 16) = v;
   }
   // bias (zero beyond Cout) behind the filter fragments and the per-wave transpose tiles
-  float* bias_s = reinterpret_cast<float*>(smem + (size_t)nks * CIN8_NI * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128);
-  if (tid < 16 * CIN8_NI) bias_s[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
+  float* bias_s = reinterpret_cast<float*>(smem + (size_t)nks * NI_ * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128);
+  if (tid < 16 * NI_) bias_s[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
+  // BatchNorm partial sums of this (persistent) workgroup: accumulated in LDS over all its tiles, ONE global atomic per
+  // channel and workgroup at the end
+  float* red_s = bias_s + 16 * NI_;       // [2][16 NI]
+  if (tid < 2 * 16 * NI_) red_s[tid] = 0.f;
   __syncthreads();
 
   const int cq = g * 4;
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
   // waves per SIMD hide the latency; an explicit next-tile prefetch at three measured the same (83 vs 85 us, enc.init).
   long long base[CIN8_NJ];
   int id0[CIN8_NJ], ih0[CIN8_NJ];
-  bool colok[CIN8_NJ];
+  bool colok[CIN8_NJ], pxok[CIN8_NJ];
   auto coords = [&](int tile) {
 #pragma unroll
     for (int j = 0; j < CIN8_NJ; ++j) {
@@ -85,55 +100,79 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
       id0[j] = (int)od * p.sd - p.pd;
       ih0[j] = (int)oh * p.sh - p.ph;
       const int iw = (int)ow * p.sw - p.pw + g;
+      pxok[j] = m < p.M;
       colok[j] = m < p.M && (unsigned)iw < (unsigned)p.Wi && g < p.kw;
       base[j] = ((((long long)n * p.Di + id0[j]) * p.Hi + ih0[j]) * p.Wi + iw) * 8;
     }
   };
-  uint4 braw[4][CIN8_NJ];
+  constexpr int NB = ROWS == 0 ? 4 : ROWS;
+  uint4 braw[NB][CIN8_NJ];
   unsigned bok = 0;
+  // generic: the <= 4 filter rows of depth tap kz; ROWS > 0: every row (kz, ky) of the filter
   auto issue = [&](int kz) {
     bok = 0;
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int j = 0; j < CIN8_NJ; ++j) {
-        const bool ok = colok[j] && ky < p.kh && (unsigned)(id0[j] + kz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
-        const long long off = ok ? base[j] + ((long long)kz * p.Hi + ky) * p.Wi * 8 : 0;
-        braw[ky][j] = *reinterpret_cast<const uint4*>(p.x + off);
-        bok |= ok ? 1u << (ky * CIN8_NJ + j) : 0u;
-      }
-  };
-
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    f32x4 acc[CIN8_NI][CIN8_NJ];
-#pragma unroll
-    for (int i = 0; i < CIN8_NI; ++i)
-#pragma unroll
-      for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kz = 0; kz < p.kd; ++kz) {
-      if (kz == 0) coords(tile);
-      issue(kz);
-      bf16x8 b[4][CIN8_NJ];
-#pragma unroll
-      for (int ky = 0; ky < 4; ++ky)
+    for (int r = 0; r < NB; ++r) {
+      const int rz = ROWS == 0 ? kz : r / p.kh, ky = ROWS == 0 ? r : r - rz * p.kh;
+      if (ROWS != 0 || ky < p.kh) {        // wave-uniform: absent filter rows cost no loads
 #pragma unroll
         for (int j = 0; j < CIN8_NJ; ++j) {
-          uint4 v = braw[ky][j];
-          if (!((bok >> (ky * CIN8_NJ + j)) & 1u)) v = make_uint4(0, 0, 0, 0);
-          b[ky][j] = __builtin_bit_cast(bf16x8, v);
+          const bool ok = colok[j] && (unsigned)(id0[j] + rz) < (unsigned)p.Di && (unsigned)(ih0[j] + ky) < (unsigned)p.Hi;
+          const long long off = ok ? base[j] + ((long long)rz * p.Hi + ky) * p.Wi * 8 : 0;
+          braw[r][j] = *reinterpret_cast<const uint4*>(p.x + off);
+          bok |= ok ? 1u << (r * CIN8_NJ + j) : 0u;
         }
+      }
+    }
+  };
+  auto mma_rows = [&](f32x4 (&acc)[NI_][CIN8_NJ], int kz) {
 #pragma unroll
-      for (int ky = 0; ky < 4; ++ky) {
-        const int ks = kz * 4 + ky;
-        bf16x8 a[CIN8_NI];
+    for (int r = 0; r < NB; ++r) {
+      if (ROWS == 0 && r >= p.kh) continue;       // wave-uniform
+      const int ks = ROWS == 0 ? kz * p.kh + r : r;
+      bf16x8 a[NI_], b[CIN8_NJ];
 #pragma unroll
-        for (int i = 0; i < CIN8_NI; ++i)
-          a[i] = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(ks * CIN8_NI + i) * 64 + lane) * 16);
+      for (int j = 0; j < CIN8_NJ; ++j) {
+        uint4 v = braw[r][j];
+        if (!((bok >> (r * CIN8_NJ + j)) & 1u)) v = make_uint4(0, 0, 0, 0);
+        b[j] = __builtin_bit_cast(bf16x8, v);
+      }
 #pragma unroll
-        for (int i = 0; i < CIN8_NI; ++i)
+      for (int i = 0; i < NI_; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(smem + ((size_t)(ks * NI_ + i) * 64 + lane) * 16);
 #pragma unroll
-          for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[ky][j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NI_; ++i)
+#pragma unroll
+        for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (ROWS != 0 && (int)blockIdx.x < p.ntiles) {
+    coords(blockIdx.x);
+    issue(0);
+  }
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    f32x4 acc[NI_][CIN8_NJ];
+#pragma unroll
+    for (int i = 0; i < NI_; ++i)
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool pxok_t[CIN8_NJ];
+    if (ROWS == 0) {
+      for (int kz = 0; kz < p.kd; ++kz) {
+        if (kz == 0) coords(tile);
+        issue(kz);
+        mma_rows(acc, kz);
+      }
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) pxok_t[j] = pxok[j];
+    } else {
+      mma_rows(acc, 0);
+#pragma unroll
+      for (int j = 0; j < CIN8_NJ; ++j) pxok_t[j] = pxok[j];
+      if (tile + (int)gridDim.x < p.ntiles) {      // next tile's loads fly behind this tile's epilogue
+        coords(tile + gridDim.x);
+        issue(0);
       }
     }
 
@@ -141,10 +180,10 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
     // bytes and a wave-instruction covers 8 whole pixels (1 KiB contiguous: out pixel == m for a regular convolution)
     // instead of 16 pixels x 32 bytes.  8-byte unit u of pixel row n sits at slot u ^ n: conflict-free for the
     // ds_write_b64 (16 pixels of one unit) and for the ds_read_b128 (8 chunks of one pixel).
-    char* ot = smem + (size_t)nks * CIN8_NI * 1024 + wave * (CIN8_NJ * 16 * 128);
-    float v[CIN8_NI * CIN8_NJ * 4];
+    char* ot = smem + (size_t)nks * NI_ * 1024 + wave * (CIN8_NJ * 16 * 128);
+    float v[NI_ * CIN8_NJ * 4];
 #pragma unroll
-    for (int i = 0; i < CIN8_NI; ++i) {
+    for (int i = 0; i < NI_; ++i) {
       const float4 b4 = *reinterpret_cast<const float4*>(bias_s + i * 16 + cq);
 #pragma unroll
       for (int j = 0; j < CIN8_NJ; ++j) {
@@ -152,10 +191,31 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
         o[0] = acc[i][j][0] + b4.x; o[1] = acc[i][j][1] + b4.y; o[2] = acc[i][j][2] + b4.z; o[3] = acc[i][j][3] + b4.w;
       }
     }
+    if (p.stats != nullptr) {
+      // sum / sum of squares of (conv + bias) over this wave's valid pixels: lanes of one K group hold the same 4 channels
+      // of 16 different pixels -> shuffle over the 16 lanes, then one LDS atomic per channel and wave
+#pragma unroll
+      for (int i = 0; i < NI_; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < CIN8_NJ; ++j) {
+            const float t = pxok_t[j] ? v[(i * CIN8_NJ + j) * 4 + r] : 0.f;
+            a1 += t; a2 += t * t;
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+          if ((lane & 15) == 0) {
+            atomicAdd(red_s + i * 16 + cq + r, a1);
+            atomicAdd(red_s + 16 * NI_ + i * 16 + cq + r, a2);
+          }
+        }
+    }
     act_apply_n<true>(v, p.act, p.slope);
     if (p.act == VFD_ACT_SIGMOID) {   // pad channels stay zero (filter rows and bias beyond Cout are zero; sigmoid(0) is not)
 #pragma unroll
-      for (int i = 0; i < CIN8_NI; ++i)
+      for (int i = 0; i < NI_; ++i)
 #pragma unroll
         for (int j = 0; j < CIN8_NJ; ++j)
 #pragma unroll
@@ -166,7 +226,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
     for (int j = 0; j < CIN8_NJ; ++j) {
       const int n = lane & 15;
 #pragma unroll
-      for (int i = 0; i < CIN8_NI; ++i) {
+      for (int i = 0; i < NI_; ++i) {
         const float* o4 = v + (i * CIN8_NJ + j) * 4;
         uint2 o;
         o.x = pack2bf(o4[0], o4[1]);
@@ -182,6 +242,13 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, 4) void conv_cin8_kernel(const Cin
       if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       if (mw + px < p.M && c * 8 < p.Cop)
         *reinterpret_cast<uint4*>(p.y + (mw + px) * p.Cop + c * 8) = v;
+    }
+  }
+  if (p.stats != nullptr) {
+    __syncthreads();
+    if (tid < 2 * 16 * NI_) {
+      const int which = tid / (16 * NI_), c = tid - which * (16 * NI_);
+      if (c < p.Cout) atomicAdd(p.stats + (size_t)(blockIdx.x % VFD_STATS_REPLICAS) * 2 * p.Cop + which * p.Cop + c, red_s[tid]);
     }
   }
 }
@@ -344,32 +411,57 @@ bool small_enabled() {
 }  // namespace
 
 // Returns 1 when the layer was handled (or, with `query`, would be), 0 when it is not one of the two shapes, < 0 on error.
-int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, bool want_stats,
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
                        bool query, hipStream_t st) {
-  if (!small_enabled() || d->dtype != VFD_BF16 || want_stats) return 0;
+  if (!small_enabled() || d->dtype != VFD_BF16) return 0;
   const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
-  if (!d->transposed) {
-    if (Cip != 8 || d->kh > 4 || d->kw > 4 || d->kh * d->kw < 9 || d->Cout > 16 * CIN8_NI || d->Cout < 17 || d->kd > 4) return 0;
+  // a stride-1 transposed convolution without output padding is a regular one with reversed taps and pad k-1-p
+  const bool flip = d->transposed && d->sd == 1 && d->sh == 1 && d->sw == 1 && Cip == 8 &&
+                    d->Do == d->Di + d->kd - 1 - 2 * d->pd && d->Ho == d->Hi + d->kh - 1 - 2 * d->ph && d->Wo == d->Wi + d->kw - 1 - 2 * d->pw &&
+                    d->kd - 1 - d->pd >= 0 && d->kh - 1 - d->ph >= 0 && d->kw - 1 - d->pw >= 0;
+  if (!d->transposed || flip) {
+    // any filter of <= 4 x 4 x 4 taps over <= 8 input channels, <= 64 output channels (BatchNorm sums optional): the first
+    // convolutions of the pyramids, the (1,3,3) / (3,1,1) / 1x1x1 factors of the (2+1)D stems, and the data gradients of
+    // last layers with <= 8 output channels (they arrive here as regular convolutions only when their stride is 1 and
+    // the caller's transposed flag says so; strided ones stay with conv_igemm)
+    if (Cip != 8 || d->kh > 4 || d->kw > 4 || d->Cout > 16 * CIN8_NI || d->kd > 4) return 0;
     const long long M = (long long)d->N * d->Do * d->Ho * d->Wo;
     if (M >= 0x7fffffffLL / CIN8_TILE * CIN8_TILE || M <= 0) return 0;
     if (query) return 1;
     Cin8P p;
     p.x = reinterpret_cast<const bf16_t*>(x); p.w = reinterpret_cast<const bf16_t*>(packed);
-    p.y = reinterpret_cast<bf16_t*>(y); p.bias = bias;
+    p.y = reinterpret_cast<bf16_t*>(y); p.bias = bias; p.stats = stats;
     p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
     p.Cout = d->Cout; p.Cop = Cop;
     p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
+    p.flip = flip ? 1 : 0;
+    if (flip) { p.pd = d->kd - 1 - d->pd; p.ph = d->kh - 1 - d->ph; p.pw = d->kw - 1 - d->pw; }
     p.act = d->act; p.slope = d->slope;
     p.fWo = make_fastdiv((uint32_t)d->Wo); p.fHo = make_fastdiv((uint32_t)d->Ho); p.fDo = make_fastdiv((uint32_t)d->Do);
     p.M = M;
     p.ntiles = (int)((M + CIN8_TILE - 1) / CIN8_TILE);
-    const size_t lds = (size_t)d->kd * 4 * CIN8_NI * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128 + 16 * CIN8_NI * sizeof(float);
+    const int ni = d->Cout <= 16 ? 1 : (d->Cout <= 32 ? 2 : 4);
+    const size_t lds = (size_t)d->kd * d->kh * ni * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128 + 3 * 16 * ni * sizeof(float);
     const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
-    hipLaunchKernelGGL(conv_cin8_kernel, dim3((unsigned)blocks), dim3(64 * CIN8_WAVES), lds, st, p);
+    const int rows = d->kd * d->kh;
+    const int rsel = (rows == 1 || rows == 3 || rows == 4 || rows == 9) ? rows : 0;
+#define CIN8_LAUNCH(R_, N_) hipLaunchKernelGGL((conv_cin8_kernel<R_, N_>), dim3((unsigned)blocks), dim3(64 * CIN8_WAVES), lds, st, p)
+#define CIN8_ROWS(N_)                                   \
+    switch (rsel) {                                     \
+      case 1: CIN8_LAUNCH(1, N_); break;                \
+      case 3: CIN8_LAUNCH(3, N_); break;                \
+      case 4: CIN8_LAUNCH(4, N_); break;                \
+      case 9: CIN8_LAUNCH(9, N_); break;                \
+      default: CIN8_LAUNCH(0, N_); break;               \
+    }
+    if (ni == 1) { CIN8_ROWS(1) } else if (ni == 2) { CIN8_ROWS(2) } else { CIN8_ROWS(4) }
+#undef CIN8_ROWS
+#undef CIN8_LAUNCH
     VFD_CHECK_LAUNCH("conv_cin8");
     return 1;
   }
   // ConvTranspose k4 s2 p1 (no output padding) on 2-D planes, thin output
+  if (stats != nullptr) return 0;
   if (d->kd != 1 || d->sd != 1 || d->pd != 0 || d->Do != d->Di) return 0;
   if (d->kh != 4 || d->kw != 4 || d->sh != 2 || d->sw != 2 || d->ph != 1 || d->pw != 1) return 0;
   if (d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi || d->Cout > 4 || d->Cout == 2) return 0;
