@@ -150,6 +150,9 @@ WG_CASES = [
     ("c3d_k133_86to96", (1, 86, 4, 11, 17), 96, (1, 3, 3), 1, (0, 1, 1), 0, False, True),   # one depth tap
     ("c2d_k3_64to48", (3, 64, 20, 24), 48, 3, 1, 1, 0, False, True),              # frames (D = 1)
     ("t3d_k3s1_128to64", (1, 128, 4, 8, 16), 64, 3, 1, 1, 0, True, True),         # transposed: (S, G) = (x, dy)
+    # gathered operand with <= 32 channels: 64-byte halo rows, two depth taps per work item (anogan NetD 32 -> 64)
+    ("c3d_k3_32to64", (2, 32, 6, 9, 20), 64, 3, 1, 1, 0, False, True),
+    ("c3d_k3_24to40", (1, 24, 5, 16, 16), 40, 3, 1, 1, 0, False, False),
 ]
 
 

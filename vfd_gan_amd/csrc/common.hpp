@@ -42,7 +42,7 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
                       const void* mul_src, int mul_act, float mul_slope, bool query, hipStream_t st);
 
 // conv_wgrad_halo.hip: halo-tiled filter gradient of stride-1 k(1|3)x3x3 layers (bf16); 1 = eligible / launched
-struct WhGeomOut { int Cs, Cg, nrt, nct, nhb, nwb, nsplit, ncols; long long nblocks, per_split; };
+struct WhGeomOut { int Cs, Cg, nrt, nct, nhb, nwb, nsplit, ncols, nkc, g32; long long nblocks, per_split; };
 int vfd_wgrad_halo_geom(const vfd_conv_desc* d, int* nsplit, size_t* bytes, WhGeomOut* out);
 int vfd_wgrad_halo_launch(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, hipStream_t st);
 

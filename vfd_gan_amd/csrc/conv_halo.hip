@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
           if (DBG & 16) { asm volatile("" : "=v"(b[j]) : "v"(baddr[j][sw] + dh_off)); continue; }
           b[j] = *reinterpret_cast<const bf16x8*>(smem + baddr[j][sw] + dh_off);
         }
-        if (DBG & 32) __builtin_amdgcn_s_setprio(1);
+        if (!(DBG & 32)) __builtin_amdgcn_s_setprio(1);      // keeps the cluster contiguous: +2 % (DBG 32 = without)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
             if (DBG & 4) { asm volatile("" :: "v"(a[i]), "v"(b[j])); continue; }
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
           }
-        if (DBG & 32) __builtin_amdgcn_s_setprio(0);
+        if (!(DBG & 32)) __builtin_amdgcn_s_setprio(0);
       }
     }
     fs ^= 1;

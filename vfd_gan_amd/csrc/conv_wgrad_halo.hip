@@ -28,6 +28,7 @@ struct WhP {
   int N, D, H, W;          // common spatial grid of S and G (stride 1, "same" padding)
   int Csp, Cs, Cgp;        // padded / logical channels of S, padded channels of G
   int kd, pd;              // depth taps, depth padding
+  int nkc;                 // depth-tap classes: kd (GCH 64: one depth tap per work item) or ceil(kd/2) (GCH 32: two)
   int ncols;               // kd*9*Cgp
   int nrt, nct;            // 64-channel tiles of S and of G
   int nhb, nwb;            // pixel blocks per plane: ceil(H/8), ceil(W/16)
@@ -54,7 +55,12 @@ __device__ __forceinline__ bf16x8 tr_pair(uint32_t lo_addr, uint32_t hi_addr) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// GCH = G channels per work item: 64 (128-byte halo rows, ONE depth tap per work item) or 32 (operands with <= 32 channels on the
+// gathered side: 64-byte rows, TWO depth taps per work item = two halo planes, so that the accumulator tile stays
+// 64 x (2 x 9 x 32) = 64 x 576 and the wave layout is unchanged: wave column wc = (plane = wc >> 1, 16-channel block = wc & 1))
+template <int GCH>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
+  constexpr int GROW = GCH * 2;                 // bytes per halo row
   __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,7 +70,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
   int item = blockIdx.x;
   const int rt = item % p.nrt; item /= p.nrt;
   const int ct = item % p.nct; item /= p.nct;
-  const int kdi = item % p.kd; item /= p.kd;
+  const int kdc = item % p.nkc; item /= p.nkc;
+  const int kdi = GCH == 64 ? kdc : 2 * kdc;          // first depth tap of this work item
   const int split = item;
   const int r0 = rt * 64, c0 = ct * 64;
   const long long b_beg = (long long)split * p.per_split;
@@ -81,7 +88,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
   // swizzled on the SOURCE side: physical slot ps of row r holds logical slot ps ^ ((r>>1)&3), (r>>1)&3 == (lane>>4)&3
   const int drow = lane >> 3;
   const int lpiece = ((((lane & 7) >> 1) ^ ((lane >> 4) & 3)) << 1) | (lane & 1);     // logical 16-byte piece (8 channels)
-  const bool s_ch_ok = r0 + lpiece * 8 < p.Csp, g_ch_ok = c0 + lpiece * 8 < p.Cgp;
+  // 64-byte G rows: 16 rows per instruction, lane -> (row lane>>2, piece lane&3), 32-byte slot swizzled by (row>>2)&1 = (lane>>4)&1
+  const int gpiece = GCH == 64 ? lpiece : (((((lane & 3) >> 1) ^ ((lane >> 4) & 1)) << 1) | (lane & 1));
+  const int grow_in_inst = GCH == 64 ? drow : (lane >> 2);
+  const bool s_ch_ok = r0 + lpiece * 8 < p.Csp, g_ch_ok = c0 + gpiece * 8 < p.Cgp;
   // position of the block to ISSUE next (2 blocks ahead of the one being computed)
   int in_, id_, ihb, iwb;
   {
@@ -97,7 +107,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
     const bool live = issued < nb;                    // blocks past the range read the zero page (uniform DMA count)
     const int h0 = ihb * 8, w0 = iwb * 16;
     const int gd = id_ + kdi - p.pd;                  // G plane of this depth tap
-    const bool gplane = live && (unsigned)gd < (unsigned)p.D;
     // S: 16 instructions, 2 per wave: rows = pixels (h0 + row/16, w0 + row%16)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -109,17 +118,21 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
       const char* src = ok ? Sg + (pix * p.Csp + r0 + lpiece * 8) * 2 : zero;
       dma16_to_lds(src, sb + inst * 1024);
     }
-    // G halo: 24 instructions (180 rows used), 3 per wave: rows = (hy, wx) of the 10 x 18 halo, pixel (h0-1+hy, w0-1+wx)
+    // G halo: 24 instructions, 3 per wave.  GCH 64: one plane of 192 rows (180 used) x 128 B; GCH 32: two planes (depth taps
+    // kdi, kdi+1) of 192 rows x 64 B.  Rows = (hy, wx) of the 10 x 18 halo, pixel (h0-1+hy, w0-1+wx)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int inst = wave + 8 * k;
-      const int row = inst * 8 + drow;
+      const int plane = GCH == 64 ? 0 : inst / 12;
+      const int row = (GCH == 64 ? inst * 8 : (inst - plane * 12) * 16) + grow_in_inst;
       const int hy = (row * 3641) >> 16;              // row / 18 for row < 192
       const int wx = row - hy * 18;
       const int h = h0 - 1 + hy, w = w0 - 1 + wx;
-      const bool ok = gplane && g_ch_ok && row < 180 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-      const size_t pix = ((size_t)(in_ * p.D + gd) * p.H + h) * p.W + w;
-      const char* src = ok ? Gg + (pix * p.Cgp + c0 + lpiece * 8) * 2 : zero;
+      const int gdp = gd + plane;
+      const bool ok = live && kdi + plane < p.kd && (unsigned)gdp < (unsigned)p.D && g_ch_ok && row < 180 &&
+                      (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+      const size_t pix = ((size_t)(in_ * p.D + gdp) * p.H + h) * p.W + w;
+      const char* src = ok ? Gg + (pix * p.Cgp + c0 + gpiece * 8) * 2 : zero;
       dma16_to_lds(src, gb + inst * 1024);
     }
     ++issued;
@@ -133,12 +146,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
   uint32_t a_addr[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) a_addr[i] = tr_addr(rowl, wr * 2 + i);                     // + 2048: rows 16..31 (same swizzle)
+  // G fragments: GCH 64: channel block wc of the single plane; GCH 32: channel block wc & 1 of plane wc >> 1 (64-byte rows:
+  // 32-byte slot p of row r at p ^ ((r>>2)&1), conflict-free for the 8 rows of a half-wave at any alignment)
+  auto tr_addr_g = [&](int row, int cb) __attribute__((always_inline)) {
+    return GCH == 64 ? row * 128 + ((cb ^ ((row >> 1) & 3)) << 5) + pp * 8 : row * 64 + ((cb ^ ((row >> 2) & 1)) << 5) + pp * 8;
+  };
+  const int gplane_rows = GCH == 64 ? 0 : (wc >> 1) * 192;
+  const int gcb = GCH == 64 ? wc : (wc & 1);
   uint32_t b_lo[9], b_hi[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const int row = (t / 3) * 18 + (t % 3) + rowl;
-    b_lo[t] = S_BYTES + tr_addr(row, wc);
-    b_hi[t] = S_BYTES + tr_addr(row + 18, wc);
+    const int row = gplane_rows + (t / 3) * 18 + (t % 3) + rowl;
+    b_lo[t] = S_BYTES + tr_addr_g(row, gcb);
+    b_hi[t] = S_BYTES + tr_addr_g(row + 18, gcb);
   }
 
   f32x4 acc[2][9];
@@ -162,7 +182,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
       const uint32_t sbase = smem_base + stage * STAGE;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        // S: +32 rows per K-step (swizzle unchanged); G: +36 halo rows per K-step: (row>>1)&3 advances by 2 -> slot ^ 2 = byte ^ 64
+        // S: +32 rows per K-step (swizzle unchanged); G: +36 halo rows per K-step: 128-byte rows: (row>>1)&3 advances by 2 ->
+        // slot ^ 2 = byte ^ 64; 64-byte rows: (row>>2)&1 flips -> slot ^ 1 = byte ^ 32
         bf16x8 a[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -171,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const uint32_t x = (ks & 1) ? 64u : 0u;
-          const bf16x8 bf = tr_pair(sbase + (b_lo[t] ^ x) + ks * 4608, sbase + (b_hi[t] ^ x) + ks * 4608);
+          const uint32_t x = (ks & 1) ? (GCH == 64 ? 64u : 32u) : 0u;
+          const bf16x8 bf = tr_pair(sbase + (b_lo[t] ^ x) + ks * (36 * GROW), sbase + (b_hi[t] ^ x) + ks * (36 * GROW));
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bf, acc[i][t], 0, 0, 0);
         }
@@ -188,12 +209,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const WhP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int c = c0 + wc * 16 + (lane & 15);
-      const int col = (kdi * 9 + t) * p.Cgp + c;
+      const int c = c0 + gcb * 16 + (lane & 15);
+      const int kdw = kdi + (GCH == 64 ? 0 : (wc >> 1));
+      const int col = (kdw * 9 + t) * p.Cgp + c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = r0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
-        if (rr < p.Cs && c < p.Cgp) slab[(size_t)rr * p.ncols + col] = acc[i][t][r];
+        if (rr < p.Cs && c < p.Cgp && kdw < p.kd) slab[(size_t)rr * p.ncols + col] = acc[i][t][r];
       }
     }
 }
@@ -217,11 +239,15 @@ int vfd_wgrad_halo_geom(const vfd_conv_desc* d, int* nsplit, size_t* bytes, WhGe
   if (d->Do != d->Di || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
   // S = dy, G = x (regular) or S = x, G = dy (transposed): same grid either way
   const int Cs = d->transposed ? d->Cin : d->Cout, Cg = d->transposed ? d->Cout : d->Cin;
-  if (Cs < 33 || Cg < 33) return 0;                 // thinner operands would leave most of a 64 x 64 tile empty
-  const int nrt = (Cs + 63) / 64, nct = (cpad(Cg) + 63) / 64;
+  // gathered side with <= 32 channels: two depth taps per work item instead (kd == 3 only: with one depth tap half of the
+  // accumulator tile would stay empty); thinner S operands would leave most of the 64-row tile empty
+  const bool g32 = Cg <= 32;
+  if (Cs < 33 || Cg < 17 || (g32 && d->kd != 3)) return 0;
+  const int nrt = (Cs + 63) / 64, nct = g32 ? 1 : (cpad(Cg) + 63) / 64;
   const int nhb = (d->Hi + 7) / 8, nwb = (d->Wi + 15) / 16;
   const long long nblocks = (long long)d->N * d->Di * nhb * nwb;
-  const int classes = nrt * nct * d->kd;
+  const int nkc = g32 ? (d->kd + 1) / 2 : d->kd;
+  const int classes = nrt * nct * nkc;
   long long ns = 256 / classes;                     // one workgroup per CU
   if (ns < 1) ns = 1;
   const long long minb = g_wgrad_halo_mode == 2 ? 1 : 8;     // at least 8 blocks per split, or the ring's fill / drain dominates
@@ -235,7 +261,7 @@ int vfd_wgrad_halo_geom(const vfd_conv_desc* d, int* nsplit, size_t* bytes, WhGe
   if (bytes) *bytes = (size_t)ns * Cs * ncols * sizeof(float);
   if (out) {
     out->Cs = Cs; out->Cg = Cg; out->nrt = nrt; out->nct = nct; out->nhb = nhb; out->nwb = nwb;
-    out->nblocks = nblocks; out->per_split = per_split; out->nsplit = (int)ns; out->ncols = ncols;
+    out->nblocks = nblocks; out->per_split = per_split; out->nsplit = (int)ns; out->ncols = ncols; out->nkc = nkc; out->g32 = g32 ? 1 : 0;
   }
   return 1;
 }
@@ -249,12 +275,13 @@ int vfd_wgrad_halo_launch(const vfd_conv_desc* d, const void* x, const void* dy,
   p.ws = reinterpret_cast<float*>(ws);
   p.N = d->N; p.D = d->Di; p.H = d->Hi; p.W = d->Wi;
   p.Cs = g.Cs; p.Csp = cpad(g.Cs); p.Cgp = cpad(g.Cg);
-  p.kd = d->kd; p.pd = d->pd;
+  p.kd = d->kd; p.pd = d->pd; p.nkc = g.nkc;
   p.ncols = g.ncols;
   p.nrt = g.nrt; p.nct = g.nct; p.nhb = g.nhb; p.nwb = g.nwb;
   p.nblocks = g.nblocks; p.per_split = g.per_split; p.nsplit = g.nsplit;
   p.fwb = make_fastdiv((uint32_t)g.nwb); p.fhb = make_fastdiv((uint32_t)g.nhb); p.fd = make_fastdiv((uint32_t)d->Di);
-  const long long nwg = (long long)g.nsplit * d->kd * g.nct * g.nrt;
-  hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)nwg), dim3(512), 0, st, p);
+  const long long nwg = (long long)g.nsplit * g.nkc * g.nct * g.nrt;
+  if (g.g32) hipLaunchKernelGGL(conv_wgrad_halo_kernel<32>, dim3((unsigned)nwg), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL(conv_wgrad_halo_kernel<64>, dim3((unsigned)nwg), dim3(512), 0, st, p);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
