@@ -197,6 +197,13 @@ int vfd_avgpool_backward(int dtype, const void* dy, void* dx, int N, int D, int 
 int vfd_upsample2x_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
 int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C,
                             void* stream);
+/* Evaluation sweep post-processing on float32 planes [planes][H][W] (a (N,1,T,H,W) mask, planes = N*T): optional
+ * threshold (x > threshold ? 1 : 0, lib/utils.py:149-152) followed by the 5 x 5 morphological opening of
+ * lib/utils.py:139-147 (cv2.morphologyEx(MORPH_OPEN, ones(5,5)) per frame; cv2's default border: outside pixels do not take
+ * part).  `tmp` holds the eroded planes.  Replaces a device -> host -> cv2 -> device round trip per test batch
+ * (models/mygannet.py:396-397, models/anogan.py:180-181). */
+int vfd_morph_open5x5(const float* x, float* tmp, float* y, int64_t planes, int H, int W, float threshold, int binarize,
+                      void* stream);
 /* dst[rows][CPAD(Ca+Cb)] = concat(a[rows][CPAD(Ca)], b[rows][CPAD(Cb)]) ; split is the backward.         */
 int vfd_concat_channels(int dtype, const void* a, const void* b, void* dst, int64_t rows, int Ca, int Cb,
                         void* stream);

@@ -1,0 +1,168 @@
+"""N2: in-loop evaluation — eval-mode BatchNorm, the device-side threshold + 5x5 opening, and the test()
+sweeps of MyGAN (reference models/mygannet.py:369-475) and AnoGAN (models/anogan.py:145-227) against the CPU oracle's
+restatement (oracle/vfd_oracle/evalsweep.py) on identical weights, clips, flows and noise."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(tmp, model, B, T, S):
+    return types.SimpleNamespace(batchsize=B, nfr=T, isize=S, ich=3, lr=2e-5, beta1=0.5, w_adv=1, w_con=10, pos_weight=2, freq=10 ** 9, ep=1,
+                                 model=model, result_root=str(tmp), gpu=[0], ae=False, resume="")
+
+
+def test_morph_open5x5_matches_restatement(dev):
+    """Threshold + 5x5 opening on the device == the scipy restatement of cv2's semantics, borders and odd sizes included."""
+    from vfd_gan_amd.lib.utils import morphology_proc, threshold
+    from vfd_oracle.evalsweep import morph_open5
+    g = torch.Generator().manual_seed(3)
+    for shape in ((2, 1, 3, 17, 23), (1, 1, 2, 64, 64), (1, 1, 1, 5, 9)):
+        x = torch.rand(shape, generator=g)
+        # blobs, so that something survives the opening
+        x = torch.nn.functional.avg_pool3d(x, (1, 5, 5), 1, (0, 2, 2)) * 1.6
+        t = (x > 0.5).float()
+        ref = morph_open5(t.numpy())
+        got = morphology_proc(threshold(x.to(dev))).cpu().numpy()
+        assert 0 < ref.sum() < ref.size
+        assert np.array_equal(got, ref), shape
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_batchnorm_eval_mode(dt, dev):
+    """nn.BatchNorm3d.eval(): running statistics, fused activation, no update of the statistics; forward-only."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F
+    from util import TOL
+    torch.manual_seed(2)
+    ref = torch.nn.Sequential(torch.nn.BatchNorm3d(13), torch.nn.LeakyReLU(0.2))
+    ref[0].running_mean.copy_(torch.randn(13) * 0.3)
+    ref[0].running_var.copy_(torch.rand(13) + 0.5)
+    with torch.no_grad():
+        ref[0].weight.copy_(torch.rand(13) + 0.5)
+        ref[0].bias.copy_(torch.randn(13) * 0.1)
+    mine = vnn.Sequential(vnn.BatchNorm3d(13), vnn.LeakyReLU(0.2))
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev)
+    ref.eval()
+    mine.eval()
+    x = torch.randn(2, 13, 3, 6, 5)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    with torch.no_grad():
+        y = mine(F.to_cl(x.to(dev), dt)).to_torch()
+    assert relerr(y, ref(x)) < TOL[dt]
+    assert torch.equal(mine[0].running_mean.cpu(), ref[0].running_mean) and int(mine[0].num_batches_tracked) == 0
+    with pytest.raises(NotImplementedError):
+        mine(F.to_cl(x.to(dev).requires_grad_(), dt))
+
+
+def test_anogan_test_sweep(dev, tmp_path):
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.lib.data import synthetic_batch
+    from vfd_gan_amd.models import anogan as HA
+    from vfd_oracle import anogan as OA
+    from vfd_oracle.evalsweep import anogan_test
+    from vfd_oracle.weights import fill_module, seeded_normal
+    F.set_compute_dtype(torch.float32)
+    B, T, S = 2, 8, 32
+    og, od = fill_module(OA.NetG(T, S), 1), fill_module(OA.NetD(T, S), 2)
+    for net in (og, od):                       # non-trivial running statistics for the eval-mode BatchNorms
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.BatchNorm1d)):
+                g = torch.Generator().manual_seed(m.num_features)
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.05)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+    batches = [synthetic_batch(B, T, S, 3, seed=400 + i) for i in range(2)]
+    zs = [seeded_normal((B, 100), 410 + i) for i in range(2)]
+    model = HA.AnoGAN(_args(tmp_path, "anogan", B, T, S), {"train": [], "test": batches})
+    model.netg.load_state_dict(og.state_dict())
+    model.netd.load_state_dict(od.state_dict())
+    F.invalidate_weight_cache()
+    ref_losses, ref_scores = anogan_test(og, od, batches, zs)
+    zdev = [z.to(dev) for z in zs]
+    # simplest: run the sweep one batch at a time with the imposed z, then compare the means
+    losses = {"gen_loss": [], "dis_loss_real": [], "dis_loss_fake": []}
+    gts, pres = [], []
+    for i in range(2):
+        model.dataloader = {"train": [], "test": [batches[i]]}
+        model.z = zdev[i]
+        model.best_roc, model.best_pr = 0, 0
+        model.test()
+        for k in losses:
+            losses[k].append(model.test_losses[k])
+        gts.append(batches[i][2].permute(0, 2, 3, 4, 1).numpy())
+        pres.append(model.hist_dict["test/predict"].permute(0, 2, 3, 4, 1).cpu().numpy())
+    assert model.netg.training and model.netd.training            # training mode restored
+    for k, v in ref_losses.items():
+        got = float(np.mean(losses[k]))
+        assert abs(got - v) <= 1e-4 * max(abs(v), 1e-3), (k, got, v)
+    from vfd_oracle.evalsweep import scores
+    got_scores = scores(np.stack(gts), np.stack(pres))
+    for k, v in ref_scores.items():
+        assert abs(got_scores[k] - v) <= 2e-3, (k, got_scores[k], v)
+    # the sweep over both batches in one call: scores through lib/evaluate.py, checkpoint on the first improvement
+    model.dataloader = {"train": [], "test": batches}
+    model.z = None
+    model.best_roc, model.best_pr = 0, 0
+    out = model.test()
+    assert 0.0 <= out["roc"] <= 1.0 and model.best_roc == out["roc"] and "score/roc" in model.score_dict
+    import os
+    assert os.path.exists(os.path.join(model.weight_dir, "roc_ep0000_netG.pth"))
+
+
+def test_mygan_test_sweep(dev, tmp_path):
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.lib.data import synthetic_batch, synthetic_flow
+    from vfd_gan_amd.models import mygannet as HM
+    from vfd_oracle import mygannet as OM
+    from vfd_oracle.evalsweep import mygan_test
+    from vfd_oracle.weights import fill_module
+    F.set_compute_dtype(torch.float32)
+    B, T, S = 2, 16, 64
+    og, od = fill_module(OM.NetG(), 3).train(), fill_module(OM.NetD(OM.make_args(T, S)), 4).train()
+    for mm in og.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+    batches = [synthetic_batch(B, T, S, 3, seed=500 + i) for i in range(2)]
+    flows = [(synthetic_flow(B, T, S, 510 + i), synthetic_flow(B, T, S, 520 + i)) for i in range(2)]
+    model = HM.MyGAN(_args(tmp_path, "mygan", B, T, S), {"train": [], "test": batches})
+    model.netg.load_state_dict(og.state_dict())
+    model.netd.load_state_dict(od.state_dict())
+    for mm in model.netg.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+    F.invalidate_weight_cache()
+    ref_errs, ref_scores = mygan_test(og, od, batches, flows)
+    out = model.test(flows=lambda i, b: flows[i])
+    for k, v in ref_errs.items():
+        got = float(model.errors_dict[k])
+        assert abs(got - v) <= 2e-4 * max(abs(v), 1e-3), (k, got, v)
+    # the thresholded + opened masks are binary: a prediction within rounding of 0.5 may land on the other side, so the
+    # scores are compared with a small absolute tolerance
+    for k, v in ref_scores.items():
+        assert abs(out[k] - v) <= 5e-3, (k, out[k], v)
+    # the reference's sweep leaves the nets in training mode and advances BatchNorm's batch counters
+    assert model.netg.training and int(model.netg.dconv1.bn.num_batches_tracked) == int(og.dconv1.bn.num_batches_tracked) == 2
+
+
+def test_train_loop_runs_the_sweep(dev, tmp_path):
+    """GANBaseModel.train() (reference lib/train_gan.py:72-80): every `freq` steps the model's test() sweep and the summary
+    update run inside the loop; scores land in score_dict and the scalar log."""
+    import json
+    import os
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd import trainer
+    F.set_compute_dtype(torch.float32)
+    a = _args(tmp_path, "anogan", 2, 8, 16)
+    a.freq, a.steps_per_epoch = 1, 2
+    m = trainer.main(a)
+    assert m.global_step == 2 and set(m.score_dict) == {"score/roc", "score/pr", "score/f1"}
+    assert 'd/err_d/test' in m.errors_dict and m.netg.training
+    log = [json.loads(line) for line in open(os.path.join(m.save_root_dir, "runs", "scalars.jsonl"))]
+    assert any(r["tag"] == "score/roc" for r in log)

@@ -567,6 +567,25 @@ def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, ac
     return ClTensor(y, x.C, x.nsp)
 
 
+def bn_act_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, act=_lib.ACT_NONE, slope=0.0):
+    """Evaluation-mode batch normalisation (torch.nn.BatchNormNd.eval(): the running statistics, no update) followed by `act`,
+    through the same normalise+activate kernel as training (vfd_bn_act_forward) with mean = running_mean and
+    rstd = 1/sqrt(running_var + eps).  Inference only — the reference evaluates under torch.no_grad()
+    (models/anogan.py:146-158); a gradient through frozen statistics is not provided."""
+    if torch.is_grad_enabled() and x.t.requires_grad:
+        raise NotImplementedError("eval-mode BatchNorm is forward-only (run it under torch.no_grad(), as the reference's test() does)")
+    if running_mean is None or running_var is None:
+        raise RuntimeError("eval-mode BatchNorm needs running statistics (track_running_stats=True)")
+    xt = x.t.contiguous()
+    rows = xt.numel() // xt.shape[-1]
+    rstd = torch.rsqrt(running_var.float() + eps)              # C floats: parameter preparation, not tensor arithmetic
+    y = torch.empty_like(xt)
+    g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+    check(load().vfd_bn_act_forward(dtype_code(xt.dtype), xt.data_ptr(), y.data_ptr(), rows, x.C, running_mean.data_ptr(),
+                                    rstd.data_ptr(), ptr(g_), ptr(b_), int(act), float(slope), stream()), "bn_act_forward(eval)")
+    return ClTensor(y, x.C, x.nsp)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # element-wise activation
 # ---------------------------------------------------------------------------------------------------------

@@ -65,6 +65,42 @@ def gray2rgb(video):
 
 
 def threshold(data):
-    """Reference lib/utils.py:149-152 (summaries only; off the numerical path)."""
+    """Reference lib/utils.py:149-152: (data > 0.5) as float, reference layout."""
     t = data.to_torch() if isinstance(data, ClTensor) else data
     return (t > 0.5).float()
+
+
+def morphology_proc(video):
+    """Reference lib/utils.py:139-147: 5 x 5 morphological opening of every frame of a (N,1,T,H,W) mask — there on the CPU
+    through cv2 with a device -> host -> device round trip, here one HIP launch pair on the device (vfd_morph_open5x5;
+    cv2's default border: pixels outside the frame do not take part).  Returns a float32 device tensor of the input's shape."""
+    from .._lib import check, load, require_device, stream
+    t = video.to_torch() if isinstance(video, ClTensor) else video
+    require_device(t)
+    t = t.contiguous().float()
+    if t.dim() < 3:
+        raise RuntimeError("morphology_proc expects (..., H, W) frames")
+    H, W = int(t.shape[-2]), int(t.shape[-1])
+    planes = t.numel() // (H * W)
+    tmp, out = torch.empty_like(t), torch.empty_like(t)
+    check(load().vfd_morph_open5x5(t.data_ptr(), tmp.data_ptr(), out.data_ptr(), planes, H, W, 0.0, 0, stream()), "morph_open5x5")
+    return out
+
+
+def normalize(tensor):
+    """Reference lib/utils.py:81-89: shift to the range (0, 1)."""
+    mn, mx = float(tensor.min()), float(tensor.max())
+    return (tensor.clamp(min=mn, max=mx) - mn) / (mx - mn + 1e-5)
+
+
+def rgb_to_gray(video):
+    """cv2.COLOR_RGB2GRAY of reference lib/utils.py:131-136 on a (N,3,T,H,W) device tensor: 0.299 R + 0.587 G + 0.114 B."""
+    return (0.299 * video[:, 0:1] + 0.587 * video[:, 1:2] + 0.114 * video[:, 2:3])
+
+
+def predict_forg(gout, input):
+    """Reference models/anogan.py:24-37: |gout - input|, every FRAME (all clips, all channels of time step t) shifted to
+    (0,1) on its own, then grey — on the device, (N,1,T,H,W) out."""
+    diff = torch.abs(gout - input)
+    frames = [normalize(diff[:, :, t]) for t in range(diff.shape[2])]       # reference normalises per time step over (B,C,H,W)
+    return rgb_to_gray(torch.stack(frames, dim=2))

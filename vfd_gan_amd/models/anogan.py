@@ -173,6 +173,66 @@ class AnoGAN(GANBaseModel):
         self.errors_dict.update({'d/err_d/train': self.dis_loss, 'g/err_g/train': self.gen_loss,
                                  'd/err_d_real/train': self.dis_loss_real, 'd/err_d_fake/train': self.dis_loss_fake})
 
+    def test(self):
+        """In-loop evaluation sweep, reference :145-227: both nets in EVAL mode (running BatchNorm statistics, no Dropout) under
+        torch.no_grad(); per test batch the three discriminator losses, predict = grey(normalise(|G(z) - real|))
+        (predict_forg :24-37, on the device), threshold + 5x5 opening for the summaries; ROC / PR / F1 of `predict` against
+        `gt` over all test pixels, a checkpoint when ROC (else PR) improves.  The reference leaves the nets in eval mode
+        afterwards and its optimize_params never switches back (models/anogan.py has no .train() call in the step); here
+        training mode is restored, as the per-step BatchNorm statistics of the training step require."""
+        import numpy as np
+        from ..lib.evaluate import evaluate
+        from ..lib.utils import morphology_proc, predict_forg, threshold
+        was_training = self.netg.training
+        self.netg.eval()
+        self.netd.eval()
+        gen_loss_, dis_loss_real_, dis_loss_fake_ = [], [], []
+        gts, predicts = [], []
+        try:
+            with torch.no_grad():
+                for i, data in enumerate(self.dataloader['test']):
+                    input, real, gt, lb = (d.to(self.device, non_blocking=True) for d in data)
+                    real_cl = F.to_cl(real)
+                    dis_loss_real_.append(self.loss(self.netd(real_cl)[0], self.ones_label))
+                    z = self.z if self.z is not None else torch.randn(self.args.batchsize, 100, device=self.device)
+                    gen_fake_cl = self.netg(F.to_cl(z))
+                    dis_fake_ = self.netd(gen_fake_cl)[0]
+                    dis_loss_fake_.append(self.loss(dis_fake_, self.zeros_label))
+                    gen_loss_.append(self.loss(dis_fake_, self.ones_label))        # reference runs netd(gen_fake_) a second time: same values
+                    gen_fake_ = gen_fake_cl.to_torch()
+                    predict_ = predict_forg(gen_fake_, real)
+                    t_pre_ = threshold(predict_)
+                    m_pre_ = morphology_proc(t_pre_)
+                    gts.append(gt.permute(0, 2, 3, 4, 1))
+                    predicts.append(predict_.permute(0, 2, 3, 4, 1))
+                    self.color_video_dict.update({'test/input-real-gen': torch.cat([input, real, gen_fake_], dim=3)})
+                    self.gray_video_dict.update({'test/gt-pre-th-morph': torch.cat([gt, predict_, t_pre_, m_pre_], dim=3)})
+                    self.hist_dict.update({"test/inp": input, "test/gt": gt, "test/gen": gen_fake_, "test/predict": predict_,
+                                           "test/t_pre": t_pre_, "test/m_pre": m_pre_})
+                tonp = lambda xs: torch.stack([v.detach().float().reshape(()) for v in xs]).cpu().numpy().astype(np.float64)  # noqa: E731
+                gen_l, dr, df = tonp(gen_loss_), tonp(dis_loss_real_), tonp(dis_loss_fake_)
+                gts_np = np.asarray(torch.stack(gts).cpu().numpy(), dtype=np.int32).flatten()
+                pre_np = np.asarray(torch.stack(predicts).cpu().numpy()).flatten()
+        finally:
+            if was_training:
+                self.netg.train()
+                self.netd.train()
+        saveto = self.save_root_dir if self.rank == 0 else None
+        roc = evaluate(gts_np, pre_np, self.best_roc, self.epoch, saveto, metric='roc')
+        pr = evaluate(gts_np, pre_np, self.best_pr, self.epoch, saveto, metric='pr')
+        f1 = evaluate(gts_np, pre_np, metric='f1_score')
+        if roc > self.best_roc:
+            self.best_roc = roc
+            self.save_weights('roc')
+        elif pr > self.best_pr:
+            self.best_pr = pr
+            self.save_weights('pr')
+        self.score_dict.update({"score/roc": roc, "score/pr": pr, "score/f1": f1})
+        # the reference files the generator loss under 'd/err_d/test' and the discriminator loss under 'd/err_g/test' (:224-225)
+        self.errors_dict.update({'d/err_d/test': float(np.mean(gen_l)), 'd/err_g/test': float(np.mean(dr + df))})
+        self.test_losses = {"gen_loss": float(np.mean(gen_l)), "dis_loss_real": float(np.mean(dr)), "dis_loss_fake": float(np.mean(df))}
+        return {"roc": roc, "pr": pr, "f1": f1}
+
     def optimize_params(self):
         self._d_phase()
         self.d_opt.step()

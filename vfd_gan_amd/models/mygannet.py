@@ -277,6 +277,80 @@ class MyGAN(GANBaseModel):
         return [("graph", a), ("reduce", self.reducer_g), ("graph", b), ("reduce", self.reducer_d),
                 ("join", self.reducer_g), ("graph", c), ("join", self.reducer_d), ("graph", d)]
 
+    def test(self, flows=None):
+        """In-loop evaluation sweep, reference :369-475: the nets run under torch.no_grad() in whatever mode they are in — the
+        reference never calls .eval() here, so BatchNorm keeps using (and updating) batch statistics and Dropout stays
+        active; predict -> threshold -> 5x5 opening (on the device, lib/utils.morphology_proc), both discriminator passes,
+        the 12 loss means, ROC / PR / F1 over all test pixels (lib/evaluate.py) and a checkpoint when ROC (else PR) improves.
+        `flows(i, B)` -> (gt_flow, pre_flow) stands in for video_to_flow (CPU Farneback, SURVEY.md 8f N1: not built);
+        default: the synthetic streams training uses."""
+        import numpy as np
+        from ..lib.evaluate import evaluate
+        from ..lib.utils import morphology_proc, threshold
+        keys = ("err_g_adv_s", "err_g_adv_t", "err_g_con", "err_d_real_s", "err_d_real_t", "err_d_fake_s", "err_d_fake_t")
+        acc = {k: [] for k in keys}
+        predicts, gts = [], []
+        with torch.no_grad():
+            for i, data in enumerate(self.dataloader['test']):
+                input, real, gt, lb = (d.to(self.device, non_blocking=True) for d in data)
+                F.dropout_begin_step(self.device)
+                B = input.shape[0]
+                predict_ = self.netg(F.to_cl(input))                     # ClTensor (N,1,T,H,W)
+                p_t = predict_.to_torch()
+                t_pre_ = threshold(p_t)
+                m_pre_ = morphology_proc(t_pre_)
+                gts.append(gt.permute(0, 2, 3, 4, 1))
+                predicts.append(m_pre_.permute(0, 2, 3, 4, 1))
+                if flows is not None:
+                    gt_flow_, pre_flow_ = flows(i, B)
+                else:
+                    gt_flow_ = synthetic_flow(B, self.args.nfr, self.args.isize, seed=14321 + i)
+                    pre_flow_ = synthetic_flow(B, self.args.nfr, self.args.isize, seed=18642 + i)
+                gt_cl = F.to_cl(gt)
+                gt_3ch_, pre_3ch_ = F.gray2rgb(gt_cl), F.gray2rgb(predict_)
+                gf, pf = F.to_cl(gt_flow_.to(self.device)), F.to_cl(pre_flow_.to(self.device))
+                s_pred_real_, s_feat_real_, t_pred_real_, t_feat_real_ = self.netd(gt_3ch_, gf)
+                s_pred_fake_, s_feat_fake_, t_pred_fake_, t_feat_fake_ = self.netd(pre_3ch_, pf)
+                acc["err_g_adv_s"].append(self.l_adv(s_feat_real_, s_feat_fake_))
+                acc["err_g_adv_t"].append(self.l_adv(t_feat_real_, t_feat_fake_))
+                acc["err_g_con"].append(self.l_con(predict_, gt_cl))
+                acc["err_d_real_s"].append(self.l_bce(s_pred_real_, self.real_label))
+                acc["err_d_real_t"].append(self.l_bce(t_pred_real_, self.real_label))
+                acc["err_d_fake_s"].append(self.l_bce(s_pred_fake_, self.gout_label))
+                acc["err_d_fake_t"].append(self.l_bce(t_pred_fake_, self.gout_label))
+                self.color_video_dict.update({'test/input-real': torch.cat([input, real], dim=3)})
+                self.gray_video_dict.update({'test/gt-pre-th-morph': torch.cat([gt, p_t, t_pre_, m_pre_], dim=3)})
+                self.hist_dict.update({"test/inp": input, "test/gt": gt, "test/predict": p_t, "test/t_pre": t_pre_, "test/m_pre": m_pre_})
+            # ONE device -> host transfer for the sweep's scalars (the reference pays an .item() sync per scalar and batch)
+            e = {k: torch.stack([v.detach().float().reshape(()) for v in acc[k]]).cpu().numpy().astype(np.float64) for k in keys}
+            gts_np = np.asarray(torch.stack(gts).cpu().numpy(), dtype=np.int32).flatten()
+            pre_np = np.asarray(torch.stack(predicts).cpu().numpy()).flatten()
+        err_g_adv = e["err_g_adv_s"] + e["err_g_adv_t"]
+        err_g = e["err_g_adv_t"] * self.args.w_adv + e["err_g_con"] * self.args.w_con      # reference :416: temporal term only
+        err_d_real = (e["err_d_real_s"] + e["err_d_real_t"]) * 0.5
+        err_d_fake = (e["err_d_fake_s"] + e["err_d_fake_t"]) * 0.5
+        err_d = (err_d_real + err_d_fake) * 0.5
+        saveto = self.save_root_dir if self.rank == 0 else None
+        roc = evaluate(gts_np, pre_np, self.best_roc, self.epoch, saveto, metric='roc')
+        pr = evaluate(gts_np, pre_np, self.best_pr, self.epoch, saveto, metric='pr')
+        f1 = evaluate(gts_np, pre_np, metric='f1_score')
+        if roc > self.best_roc:
+            self.best_roc = roc
+            self.save_weights('roc')
+        elif pr > self.best_pr:
+            self.best_pr = pr
+            self.save_weights('pr')
+        self.score_dict.update({"score/roc": roc, "score/pr": pr, "score/f1": f1})
+        self.errors_dict.update({
+            'd/err_d_real_s/test': float(np.mean(e["err_d_real_s"])), 'd/err_d_real_t/test': float(np.mean(e["err_d_real_t"])),
+            'd/err_d_fake_s/test': float(np.mean(e["err_d_fake_s"])), 'd/err_d_fake_t/test': float(np.mean(e["err_d_fake_t"])),
+            'd/err_d_real/test': float(np.mean(err_d_real)), 'd/err_d_fake/test': float(np.mean(err_d_fake)),
+            'd/err_d/test': float(np.mean(err_d)),
+            'g/err_g_adv_s/test': float(np.mean(e["err_g_adv_s"])), 'g/err_g_adv_t/test': float(np.mean(e["err_g_adv_t"])),
+            'g/err_g_adv/test': float(np.mean(err_g_adv)), 'g/err_g_con/test': float(np.mean(e["err_g_con"])),
+            'g/err_g/test': float(np.mean(err_g))})
+        return {"roc": roc, "pr": pr, "f1": f1}
+
     def optimize_params(self):
         F.dropout_begin_step(self.device)
         self.netg.train()

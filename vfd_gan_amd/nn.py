@@ -94,8 +94,10 @@ class _BatchNormMixin:
         _need_cl(x, type(self).__name__)
         if x.C != self.num_features:
             raise RuntimeError("BatchNorm: %d channels, expected %d" % (x.C, self.num_features))
-        if not self.training:
-            raise NotImplementedError("eval-mode BatchNorm is off the training hot path (SURVEY.md 8f N2)")
+        if not self.training and self.track_running_stats:
+            # .eval(): normalise with the running statistics (reference models/anogan.py:146-147 puts both nets in eval mode
+            # for its test sweep); statistics handed over by a conv epilogue (`sums`) are ignored
+            return F.bn_act_eval(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, act, slope)
         if self.momentum is None:
             raise NotImplementedError("cumulative-average BatchNorm (momentum=None)")
         rm = self.running_mean if self.track_running_stats else None
