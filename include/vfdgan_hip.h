@@ -98,7 +98,7 @@ int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T
  * the per-channel sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
  * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106), one float atomic per
  * channel and workgroup, spread over replica rows; vfd_bn_stats_from_sums folds the replicas.                */
-#define VFD_STATS_REPLICAS 64
+#define VFD_STATS_REPLICAS 8
 int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                      float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Scratch bytes vfd_conv_forward wants for `d` (0 for most shapes).  Convolutions with few output pixels and a
@@ -113,6 +113,18 @@ int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes);
  * separate read-read-write pass.  No statistics, no split-K, no workspace. */
 int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                          const void* mul_src, int mul_act, float mul_slope, void* stream);
+
+/* The same hand-over for a producer that is BatchNorm + activation (nn.Sequential(Conv, BatchNorm, LeakyReLU, Conv, ...),
+ * models/ganomaly.py:52-58,102-108; models/spatiotempconv.py:48-57): `d` is the data gradient of the consumer layer,
+ * bn_x the BatchNorm's INPUT (y's shape and dtype), mean/rstd its batch statistics.  With xh = (bn_x - mean) * rstd the
+ * epilogue stores g = conv(x, packed) * act'(gamma * xh + beta) and adds the per-channel sums of g and of g * xh into
+ * sums (float32 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed): BatchNorm's backward reduce pass, without its two
+ * reads.  vfd_bn_backward_apply_sums finishes the BatchNorm backward from (g, sums).  bf16 with more than 32 output
+ * channels only (vfd_conv_bn_backward_supported); no bias, no activation of its own, no split-K, no workspace. */
+int vfd_conv_bn_backward_supported(const vfd_conv_desc* d);
+int vfd_conv_forward_bn_backward(const vfd_conv_desc* d, const void* x, const void* packed, void* y, const void* bn_x,
+                                 const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                 float slope, float* sums, size_t sums_bytes, void* stream);
 
 /* Name of the kernel vfd_conv_forward() dispatches this layer to ("conv_igemm<bf16,256c_x_128p>", "conv_cin8<bf16>",
  * "convt_thin<bf16>", ...), NUL-terminated into buf[n]: what the profiler rows of bench.py and profiles/ are keyed
@@ -169,6 +181,12 @@ int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, f
 int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int act, float slope,
                        void* stream);
+/* vfd_bn_stats_from_sums + vfd_bn_act_forward in ONE launch: every thread folds the replica rows of its 8 channels, the
+ * first row of workgroups publishes mean / rstd (saved for backward), the running statistics and the counter.       */
+int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const float* sums, float eps,
+                            float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, const float* gamma, const float* beta, int act, float slope,
+                            void* stream);
 /* Backward: g = dy*act'(.), dgamma = sum g*xhat, dbeta = sum g,
  * dx = gamma*rstd*(g - dbeta/rows - xhat*dgamma/rows).  dgamma/dbeta (scratch, [C]) are OVERWRITTEN;
  * dgamma_acc/dbeta_acc (NULL or the parameters' gradient buffers) are ACCUMULATED into.                   */
@@ -176,6 +194,13 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                         float slope, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* ws,
                         void* stream);
+
+/* The apply pass alone, for a gradient that arrives as g = dy*act'(.) with sums[VFD_STATS_REPLICAS][2][Cp] = the
+ * per-channel sums of g and g*xhat (vfd_conv_forward_bn_backward): dgamma/dbeta are published by the first row of
+ * workgroups (OVERWRITTEN; *_acc ACCUMULATED into), dx as above.  One launch instead of three.                  */
+int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C,
+                               const float* mean, const float* rstd, const float* gamma, const float* sums,
+                               float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* stream);
 
 /* Element-wise activation and its backward from the OUTPUT (all supported activations are invertible in
  * sign / expressible from y): dx = dy * act'(y).                                                          */

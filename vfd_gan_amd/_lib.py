@@ -36,6 +36,9 @@ SIGNATURES = {
     "vfd_flatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_pack_filter": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
+    "vfd_conv_bn_backward_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "vfd_conv_forward_bn_backward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
+                                             c_vp, c_sz, c_vp]),
     "vfd_conv_forward_mul": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_conv_workspace": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_sz)]),
     "vfd_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
@@ -52,6 +55,9 @@ SIGNATURES = {
     "vfd_bn_stats": (c_int, [c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_stats_from_sums": (c_int, [c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
+    "vfd_bn_act_forward_sums": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_int, c_f32, c_vp]),
+    "vfd_bn_backward_apply_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp]),

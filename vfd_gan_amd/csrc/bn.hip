@@ -197,23 +197,80 @@ template <int ACT> __device__ __forceinline__ float act_grad_in_c(float x, float
   else return 1.f;
 }
 
-template <typename T, int ACT>
+// Sums of 8 consecutive channels over the replica rows a conv epilogue wrote ([VFD_STATS_REPLICAS][2][Cp], common.hpp),
+// folded in double in replica order: every thread that owns the granule gets the same bits.
+__device__ __forceinline__ void fold_replicas8(const float* __restrict__ sums, int Cp, int g, double (&s1)[8], double (&s2)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
+#pragma unroll
+  for (int r = 0; r < VFD_STATS_REPLICAS; ++r) {
+    const float4* a = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + g * 8);
+    const float4* b = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + Cp + g * 8);
+    const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    s1[0] += a0.x; s1[1] += a0.y; s1[2] += a0.z; s1[3] += a0.w; s1[4] += a1.x; s1[5] += a1.y; s1[6] += a1.z; s1[7] += a1.w;
+    s2[0] += b0.x; s2[1] += b0.y; s2[2] += b0.z; s2[3] += b0.w; s2[4] += b1.x; s2[5] += b1.y; s2[6] += b1.z; s2[7] += b1.w;
+  }
+}
+
+// batch statistics handed over as epilogue sums (SUMS): the fold that bn_from_sums_kernel does in a launch of its own is
+// repeated by every thread for its 8 channels (32 L2-resident 16-byte loads); the row-0 workgroups publish mean / rstd
+// (saved for backward) and update the running statistics.
+struct BnSumsArg {
+  const float* sums;
+  float eps, momentum;
+  float* mean_o;
+  float* rstd_o;
+  float* rmean;
+  float* rvar;
+  long long* nbt;
+};
+
+template <typename T, int ACT, bool SUMS>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int TX,
                                                          long long rpb, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float slope) {
+                                                         const float* __restrict__ beta, float slope, BnSumsArg sa) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
+  if constexpr (SUMS) {
+    if (sa.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sa.nbt += 1;      // BatchNorm.num_batches_tracked
+  }
   if (g >= GR) return;
   float sc[8], sf[8];
+  if constexpr (SUMS) {
+    double s1[8], s2[8];
+    fold_replicas8(sa.sums, Cp, g, s1, s2);
+    const double n = (double)rows, inv_n = 1.0 / n;
+    const bool publish = blockIdx.y == 0 && ty == 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int c = g * 8 + k;
-    if (c < C) {
-      sc[k] = rstd[c] * (gamma ? gamma[c] : 1.f);
-      sf[k] = (beta ? beta[c] : 0.f) - mean[c] * sc[k];
-    } else { sc[k] = 0.f; sf[k] = 0.f; }
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      const double mu = s1[k] * inv_n;
+      double m2 = s2[k] - s1[k] * mu;
+      if (m2 < 0) m2 = 0;
+      const float var = (float)(m2 * inv_n);
+      const float rs = 1.f / sqrtf(var + sa.eps);
+      if (c < C) {
+        sc[k] = rs * (gamma ? gamma[c] : 1.f);
+        sf[k] = (beta ? beta[c] : 0.f) - (float)mu * sc[k];
+        if (publish) {
+          sa.mean_o[c] = (float)mu;
+          sa.rstd_o[c] = rs;
+          if (sa.rmean != nullptr) sa.rmean[c] = (1.f - sa.momentum) * sa.rmean[c] + sa.momentum * (float)mu;
+          if (sa.rvar != nullptr) sa.rvar[c] = (1.f - sa.momentum) * sa.rvar[c] + sa.momentum * (float)(n > 1 ? m2 / (n - 1) : m2 * inv_n);
+        }
+      } else { sc[k] = 0.f; sf[k] = 0.f; }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      if (c < C) {
+        sc[k] = rstd[c] * (gamma ? gamma[c] : 1.f);
+        sf[k] = (beta ? beta[c] : 0.f) - mean[c] * sc[k];
+      } else { sc[k] = 0.f; sf[k] = 0.f; }
+    }
   }
   const long long rbeg = (long long)blockIdx.y * rpb;
   long long rend = rbeg + rpb;
@@ -371,6 +428,66 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   }
 }
 
+// ---- backward apply for a BatchNorm whose gradient arrives as g = dy * act'(z) with the sums of g and g * xhat in replica
+// rows (written by the consumer convolution's data-gradient epilogue, conv_epilogue.hpp): the reduce pass and the finalize
+// launch are gone; the row-0 workgroups publish dgamma / dbeta.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restrict__ x, const T* __restrict__ gz, T* __restrict__ dx,
+                                                                long long rows, int C, int TX, long long rpb,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc) {
+  const int Cp = (C + 7) & ~7, GR = Cp >> 3;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+  const int g = blockIdx.x * TX + tx;
+  if (g >= GR) return;
+  float mu[8], rs[8], gr[8], c1[8], c2[8];
+  const float inv = 1.f / (float)rows;
+  {
+    double s1[8], s2[8];
+    fold_replicas8(sums, Cp, g, s1, s2);
+    const bool publish = blockIdx.y == 0 && ty == 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = g * 8 + k;
+      const bool ok = c < C;
+      const float sg = (float)s1[k], sgx = (float)s2[k];
+      mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
+      gr[k] = ok ? (gamma ? gamma[c] : 1.f) * rs[k] : 0.f;
+      c1[k] = ok ? sg * inv : 0.f; c2[k] = ok ? sgx * inv : 0.f;
+      if (ok && publish) {
+        dbeta[c] = sg;
+        dgamma[c] = sgx;
+        if (dbeta_acc != nullptr) dbeta_acc[c] += sg;       // parameter-gradient arena (one writer per channel)
+        if (dgamma_acc != nullptr) dgamma_acc[c] += sgx;
+      }
+    }
+  }
+  const long long rbeg = (long long)blockIdx.y * rpb;
+  long long rend = rbeg + rpb;
+  if (rend > rows) rend = rows;
+  for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
+    float v[ROWS_U][8], d[ROWS_U][8];
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+      const long long rc = ru < rend ? ru : r;
+      load8(x + rc * Cp + g * 8, v[u]);
+      load8(gz + rc * Cp + g * 8, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS_U; ++u) {
+      const long long ru = r + (long long)u * TY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (v[u][k] - mu[k]) * rs[k];
+        d[u][k] = gr[k] * (d[u][k] - c1[k] - xh * c2[k]);
+      }
+      if (ru < rend) store8(dx + ru * Cp + g * 8, d[u]);
+    }
+  }
+}
+
 }  // namespace
 
 // launch M(T, ACT) for the runtime (dtype, act) pair
@@ -431,10 +548,46 @@ extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t row
   VFD_REQUIRE(x && y && mean && rstd && rows > 0 && C > 0, "bn_act_forward: bad arguments");
   const Tiling t = make_stream_tiling(rows, C);
   dim3 grid(t.gx, t.gy);
-#define BN_FWD(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
+  BnSumsArg sa = {};
+#define BN_FWD(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_, false>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope, sa)
   BN_ACT_DISPATCH(BN_FWD);
 #undef BN_FWD
   VFD_CHECK_LAUNCH("bn_act_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const float* sums, float eps,
+                                       float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, const float* gamma, const float* beta, int act, float slope,
+                                       void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_forward_sums: bad dtype");
+  VFD_REQUIRE(x && y && sums && mean && rstd && rows > 0 && C > 0, "bn_act_forward_sums: bad arguments");
+  VFD_REQUIRE(((uintptr_t)sums & 15) == 0, "bn_act_forward_sums: the sums buffer must be 16-byte aligned");
+  const Tiling t = make_stream_tiling(rows, C);
+  dim3 grid(t.gx, t.gy);
+  BnSumsArg sa;
+  sa.sums = sums; sa.eps = eps; sa.momentum = momentum; sa.mean_o = mean; sa.rstd_o = rstd;
+  sa.rmean = running_mean; sa.rvar = running_var; sa.nbt = reinterpret_cast<long long*>(num_batches_tracked);
+#define BN_FWD(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_, true>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, (long long)rows, C, t.TX, t.rows_per_block, nullptr, nullptr, gamma, beta, slope, sa)
+  BN_ACT_DISPATCH(BN_FWD);
+#undef BN_FWD
+  VFD_CHECK_LAUNCH("bn_act_forward_sums");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C, const float* mean,
+                                          const float* rstd, const float* gamma, const float* sums, float* dgamma, float* dbeta,
+                                          float* dgamma_acc, float* dbeta_acc, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_backward_apply_sums: bad dtype");
+  VFD_REQUIRE(x && g && dx && mean && rstd && sums && dgamma && dbeta && rows > 0 && C > 0, "bn_backward_apply_sums: bad arguments");
+  VFD_REQUIRE(((uintptr_t)sums & 15) == 0, "bn_backward_apply_sums: the sums buffer must be 16-byte aligned");
+  const Tiling t = make_stream_tiling(rows, C);
+  dim3 grid(t.gx, t.gy);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_sums_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_sums_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)g, (float*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+  VFD_CHECK_LAUNCH("bn_backward_apply_sums");
   return VFD_OK;
 }
 

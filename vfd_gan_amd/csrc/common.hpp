@@ -37,9 +37,27 @@ void vfd_set_error(const char* fmt, ...);
 int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
                        bool query, hipStream_t st);
 
+// Gradient hand-over carried by the epilogue of a data-gradient convolution (conv_epilogue.hpp): the consumer layer's
+// dgrad leaves already multiplied by the derivative of the producer's activation.
+//   src only            : y *= act'(src), src = the producer's activation OUTPUT (conv -> act -> conv chains)
+//   src + bn_mean ...   : src = the producer BatchNorm's INPUT x; with xh = (x - mean) * rstd the epilogue stores
+//                         g = y * act'(gamma * xh + beta) and adds the per-channel sums of g and g * xh into bn_sums
+//                         ([VFD_STATS_REPLICAS][2][Cop], zeroed by the caller): BatchNorm's backward reduce pass
+struct MulP {
+  const void* src;
+  int act;
+  float slope;
+  const float* bn_mean;
+  const float* bn_rstd;
+  const float* bn_gamma;   // null: 1
+  const float* bn_beta;    // null: 0
+  float* bn_sums;
+};
+static inline MulP no_mul() { MulP m; m.src = nullptr; m.act = 0; m.slope = 0.f; m.bn_mean = m.bn_rstd = m.bn_gamma = m.bn_beta = nullptr; m.bn_sums = nullptr; return m; }
+
 // conv_halo.hip: same return convention; unit-input-stride layers with <= 64 output channels (bf16)
 int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
-                      const void* mul_src, int mul_act, float mul_slope, bool query, hipStream_t st);
+                      const MulP& mul, bool query, hipStream_t st);
 
 // conv_wgrad_halo.hip: halo-tiled filter gradient of stride-1 k(1|3)x3x3 layers (bf16); 1 = eligible / launched
 struct WhGeomOut { int Cs, Cg, nrt, nct, nhb, nwb, nsplit, ncols, nkc, g32; long long nblocks, per_split; };

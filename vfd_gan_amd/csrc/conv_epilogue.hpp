@@ -1,5 +1,5 @@
 // Epilogue shared by the MFMA convolution kernels (conv_igemm.hip, conv_halo.hip): bias, BatchNorm partial sums,
-// activation, optional multiply by act'(mul_src), channels-last store.
+// activation, optional gradient hand-over (MulP: multiply by act', BatchNorm backward sums), channels-last store.
 //
 // Accumulator layout (both kernels): wave w owns channels [wave_c0, +NI*16) x tile rows (pixels) [wave_p0, +NJ*16) with
 // wave_c0 = (w % WAVES_C) * NI*16, wave_p0 = (w / WAVES_C) * NJ*16; acc[i][j][r] = channel wave_c0 + 16 i + 4 (lane>>4) + r
@@ -18,12 +18,10 @@ struct EpiP {
   int Cop, Cout;
   int act;
   float slope;
-  const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape)
-  int mul_act;
-  float mul_slope;
+  MulP mul;              // mul.src non-null: gradient hand-over (common.hpp), mul.src has y's shape
 };
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, typename OutOff, typename RowValid>
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, bool BN, typename OutOff, typename RowValid>
 __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], const EpiP& p, int n0, int stats_replica,
                                               OutOff out_offset, RowValid row_valid) {
   constexpr int TILE_C = WAVES_C * NI * 16;
@@ -37,7 +35,10 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // (channel-tile outer loop: only 4 bias values and 8 statistic partials are live at a time; the activation is
   // dispatched ONCE around the loops: a per-value switch is replicated, branches included, in every unrolled copy)
   T* __restrict__ yg = reinterpret_cast<T*>(p.y);
-  const bool want_stats = p.stats != nullptr;
+  // BN (a kernel variant of its own: as a runtime branch its registers spill the plain kernels): the BatchNorm hand-over
+  // of MulP.  It rides on the statistics machinery below with other summands: per channel, the sums of g = y * act'(z)
+  // and of g * xh instead of y and y^2, added into mul.bn_sums.
+  const bool want_stats = BN || p.stats != nullptr;
   // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
@@ -49,6 +50,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   constexpr int HALF_P = VIA_LDS ? TILE_P / NH : TILE_P;
   constexpr int OUT_BYTES = VIA_LDS ? HALF_P * TILE_C * 2 : 0;
   static_assert(OUT_BYTES + RED_BYTES + TILE_P * 8 <= RING_BYTES, "epilogue LDS exceeds the staging LDS");
+  static_assert(!BN || VIA_LDS, "the BatchNorm hand-over is built on the row-store epilogue (bf16, >= 64-channel tiles)");
   // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
   // same 2*Cout addresses; bn_from_sums folds the replicas).
@@ -65,6 +67,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   if (VIA_LDS || want_stats) __syncthreads();      // every wave is done reading the last stage
   if constexpr (VIA_LDS) {
     for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(r);
+    if constexpr (BN) __syncthreads();      // the accumulator pass below already needs the row offsets
   }
   // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
   // accumulator tile across a store phase); the statistics of all sub-tiles are taken in pass 0
@@ -81,16 +84,47 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
       }
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      // BatchNorm hand-over: xh = x * ka + kb, z = xh * kg + kt for this lane's 4 channels; the producer BatchNorm's input
+      // x at this lane's (pixel, 4 channels) positions, all loads of the pass in flight before the first use
+      float ka[4], kb[4], kg[4], kt[4];
+      uint2 xv[NJ];
+      if constexpr (BN) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (c + r) < p.Cout;
+          ka[r] = ok ? p.mul.bn_rstd[c + r] : 0.f;
+          kb[r] = ok ? -p.mul.bn_mean[c + r] * ka[r] : 0.f;
+          kg[r] = ok ? (p.mul.bn_gamma != nullptr ? p.mul.bn_gamma[c + r] : 1.f) : 0.f;
+          kt[r] = (ok && p.mul.bn_beta != nullptr) ? p.mul.bn_beta[c + r] : 0.f;
+        }
+#pragma unroll
+        for (int j = H * JN; j < (H + 1) * JN; ++j) {
+          const long long off = orow[wave_p0 + j * 16 + (lane & 15)];
+          xv[j] = make_uint2(0u, 0u);
+          if (off >= 0 && c < p.Cop) xv[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.mul.src) + off + c);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const bool emit = j >= H * JN && j < (H + 1) * JN;     // compile-time after unrolling
-        if (!emit && H != 0) continue;
+        if (!emit && (H != 0 || BN)) continue;
         float v[4];
+        if constexpr (BN) {
+          const float xf[4] = {bf2f((bf16_t)(xv[j].x & 0xffffu)), bf2f((bf16_t)(xv[j].x >> 16)), bf2f((bf16_t)(xv[j].y & 0xffffu)), bf2f((bf16_t)(xv[j].y >> 16))};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = acc[i][j][r] + b4[r];
-          if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
-          v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
+          for (int r = 0; r < 4; ++r) {
+            const float xh = xf[r] * ka[r] + kb[r];
+            const float t = acc[i][j][r] * act_grad_from_in(xh * kg[r] + kt[r], p.mul.act, p.mul.slope);
+            if (pvalid[j]) { s1[r] += t; s2[r] += t * xh; }
+            v[r] = ((c + r) < p.Cout) ? t : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float t = acc[i][j][r] + b4[r];
+            if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+            v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
+          }
         }
         if (!emit) continue;
         if constexpr (VIA_LDS) {
@@ -102,10 +136,10 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
         } else {
           if (opix[j] >= 0 && c < p.Cop) {
             T* dst = yg + opix[j] + c;
-            if (p.mul_src != nullptr) {
-              const T* ms = reinterpret_cast<const T*>(p.mul_src) + opix[j] + c;
+            if (p.mul.src != nullptr) {
+              const T* ms = reinterpret_cast<const T*>(p.mul.src) + opix[j] + c;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(Elem<T>::ld(ms + r), p.mul_act, p.mul_slope);
+              for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(Elem<T>::ld(ms + r), p.mul.act, p.mul.slope);
             }
             if constexpr (sizeof(T) == 2) {
               uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
@@ -116,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           }
         }
       }
-      if (H == 0 && want_stats) {
+      if ((H == 0 || BN) && want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float a = s1[r], b = s2[r];
@@ -124,6 +158,10 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
           if ((lane & 15) == 0) {
             const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
+            if (BN && H != 0) {        // the hand-over sums are taken as the sub-tiles are emitted: pass 1 adds to pass 0 (same lane)
+              a += red[cl * WAVES_P + (wave / WAVES_C)];
+              b += red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)];
+            }
             red[cl * WAVES_P + (wave / WAVES_C)] = a;
             red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
           }
@@ -139,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     constexpr int U = NH == 1 ? 4 : 2;        // rows in flight per lane (two passes: half the waves still hold their tile)
     const int c = lane % CPRW;
     const bool cok = n0 + c * 8 < p.Cop;
-    const bf16_t* ms = reinterpret_cast<const bf16_t*>(p.mul_src);
+    const bf16_t* ms = BN ? nullptr : reinterpret_cast<const bf16_t*>(p.mul.src);     // BN: multiplied in the accumulator pass
     for (int it0 = wave; it0 < NIT; it0 += U * NWAVES) {
       long long off[U];
       uint4 v[U], mv[U];
@@ -168,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           load8(reinterpret_cast<const bf16_t*>(&v[u]), f);
           load8(reinterpret_cast<const bf16_t*>(&mv[u]), m);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul_act, p.mul_slope);
+          for (int k = 0; k < 8; ++k) f[k] *= act_grad_from_out(m[k], p.mul.act, p.mul.slope);
           store8(reinterpret_cast<bf16_t*>(&v[u]), f);
         }
         if (off[u] >= 0) *reinterpret_cast<uint4*>(yg + off[u] + n0 + c * 8) = v[u];
@@ -199,7 +237,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     }
   }
   if (want_stats) {
-    float* rep = p.stats + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    float* rep = (BN ? p.mul.bn_sums : p.stats) + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
     for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
       const int which = t / TILE_C, cl = t - which * TILE_C;
       float v = 0.f;

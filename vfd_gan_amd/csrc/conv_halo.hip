@@ -70,7 +70,8 @@ struct HaloCfg {
   static constexpr int NFW = (3 * NI + 3) / 4;                // filter DMA instructions per wave and stage (upper bound)
 };
 
-// DBG (tuning builds only, env VFD_HALO_DBG; results are WRONG): 1 = no LDS-DMA inside the loop, 2 = no barrier inside the
+// DBG bit 64 = the BatchNorm hand-over epilogue (a production variant, conv_epilogue.hpp BN).  The other DBG bits (tuning
+// builds only, env VFD_HALO_DBG; results are WRONG): 1 = no LDS-DMA inside the loop, 2 = no barrier inside the
 // loop, 4 = no MFMA, 8 = no main loop (prologue + epilogue only), 16 = no fragment reads
 template <int TILE_C, int TD, int TH, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
     if (!row_q(r, qd, qh, qw)) return -1;
     return (((long long)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r) * p.e.Cop;
   };
-  conv_epilogue<bf16_t, 1, 4, NI, NJ, C::LDS>(smem, acc, p.e, n0, (int)(item & 0x7fffffff) + cls_id, out_offset,
+  conv_epilogue<bf16_t, 1, 4, NI, NJ, C::LDS, (DBG & 64) != 0>(smem, acc, p.e, n0, (int)(item & 0x7fffffff) + cls_id, out_offset,
                                              [&](int r) { int a_, b_, c_; return row_q(r, a_, b_, c_); });
 }
 
@@ -315,6 +316,13 @@ int launch_halo(const HaloP& p, hipStream_t st) {
     }
   }
 #endif
+  if constexpr (TILE_C == 64) {
+    if (p.e.mul.bn_mean != nullptr) {      // BatchNorm hand-over: epilogue variant of its own (DBG bit 64, conv_epilogue.hpp)
+      hipLaunchKernelGGL((conv_halo_kernel<TILE_C, TD, TH, 64>), dim3((unsigned)nwg), dim3(256), 0, st, p);
+      return hipGetLastError() == hipSuccess ? 1 : -1;
+    }
+  }
+  if (p.e.mul.bn_mean != nullptr) return 0;   // 32-channel tiles leave through the direct store: conv_igemm refuses in turn
   hipLaunchKernelGGL((conv_halo_kernel<TILE_C, TD, TH>), dim3((unsigned)nwg), dim3(256), 0, st, p);
   return hipGetLastError() == hipSuccess ? 1 : -1;
 }
@@ -331,7 +339,7 @@ extern "C" int vfd_conv_set_halo_mode(int mode) {
 
 // 1 = handled (or, with query, would be handled), 0 = not a halo shape, < 0 = launch error
 int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
-                      const void* mul_src, int mul_act, float mul_slope, bool query, hipStream_t st) {
+                      const MulP& mul, bool query, hipStream_t st) {
   if (g_halo_mode < 0) g_halo_mode = getenv("VFD_NO_HALO") != nullptr ? 1 : 0;
   if (g_halo_mode == 1 || d->dtype != VFD_BF16) return 0;
   const int k[3] = {d->kd, d->kh, d->kw}, s[3] = {d->sd, d->sh, d->sw}, pp[3] = {d->pd, d->ph, d->pw};
@@ -345,7 +353,7 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
   HaloP p;
   p.x = x; p.w = packed;
   p.e.y = y; p.e.bias = bias; p.e.stats = stats; p.e.Cop = cpad(d->Cout); p.e.Cout = d->Cout; p.e.act = d->act; p.e.slope = d->slope;
-  p.e.mul_src = mul_src; p.e.mul_act = mul_act; p.e.mul_slope = mul_slope;
+  p.e.mul = mul;
   p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = cpad(d->Cin);
   p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
   p.kh = d->kh; p.kw = d->kw;

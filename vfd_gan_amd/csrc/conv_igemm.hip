@@ -45,9 +45,7 @@ struct ConvP {
   int dim_tab;           // 1: dims[][] below is valid
   DimClass dims[3][DIM_TAB];   // [d,h,w][output class r]: built on the host (make_dim_host), so that a workgroup's setup
                                // is scalar loads instead of ~15 integer divisions (one of them 64-bit) per dimension
-  const void* mul_src;   // non-null: y *= act'(mul_src) elementwise (mul_src has y's shape): activation gradient of the producer layer
-  int mul_act;
-  float mul_slope;
+  MulP mul;     // mul.src non-null: gradient hand-over in the epilogue (common.hpp)
 };
 
 
@@ -149,7 +147,7 @@ __device__ uint4 g_zero_page[4];
 // ring, ONE raw s_barrier per K-step, counted vmcnt so that STAGES-2 future steps stay in flight across the barrier.
 // The LDS image is lane-linear per wave-instruction (row = lane/4, 16-byte slot = lane%4), so the bank swizzle of
 // lds_off() is applied to the SOURCE: slot s of row r is fed logical chunk s ^ sw(r).
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB>
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3 : ((STAGES * KSUB <= 3 && NI * NJ <= 16) ? 4 : 2))) void conv_igemm_kernel(const ConvP p) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   // ---- epilogue: bias, statistics, activation, channels-last store (conv_epilogue.hpp) ----------------------
   EpiP e;
   e.y = p.y; e.bias = p.bias; e.stats = p.stats; e.Cop = p.Cop; e.Cout = p.Cout; e.act = p.act; e.slope = p.slope;
-  e.mul_src = p.mul_src; e.mul_act = p.mul_act; e.mul_slope = p.mul_slope;
+  e.mul = p.mul;
   auto out_offset = [&](int r) -> long long {       // tile row -> element offset of the output pixel, or -1
     const long long m = m0 + r;
     if (m >= Mcls) return -1;
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     const int n = (int)q;
     return ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
   };
-  conv_epilogue<T, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES>(smem, acc, e, n0, ptile + cls_id, out_offset,
+  conv_epilogue<T, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES, BN>(smem, acc, e, n0, ptile + cls_id, out_offset,
                                                                                 [&](int r) { return m0 + r < Mcls; });
 }
 
@@ -430,7 +428,7 @@ int pick_ksplit(const ConvP& p, long long M, int bk) {
   return ks < 2 ? 1 : (int)ks;
 }
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB>
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false>
 int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
@@ -447,7 +445,7 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
     }
   }
   ConvP q = p;
-  q.ksplit = p.mul_src != nullptr ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
+  q.ksplit = p.mul.src != nullptr ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
@@ -459,7 +457,7 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   const long long nwg = (long long)q.mbp * q.ny * ncls;
   if (nwg >= 0x7fffffffLL || q.ksplit > 65535) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
   dim3 grid((unsigned)nwg, 1, (unsigned)q.ksplit);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB, BN>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
   if (q.ksplit > 1) {
     const long long total = maxM * (p.Cop >> 3);
@@ -474,6 +472,17 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
 
 template <typename T>
 int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (p.mul.bn_mean != nullptr) {      // BatchNorm hand-over: the default tile of each channel range, in its BN variant
+      if (p.Cout > 128) return launch_cfg<T, 4, 4, 4, 4, 2, 2, true>(p, maxM, ncls, st, ws_bytes, ws_query);
+      if (p.Cout > 64) return launch_cfg<T, 2, 4, 4, 4, 3, 1, true>(p, maxM, ncls, st, ws_bytes, ws_query);
+      if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4, 3, 1, true>(p, maxM, ncls, st, ws_bytes, ws_query);
+      vfd_set_error("conv: the BatchNorm hand-over needs more than 32 output channels");
+      return VFD_EINVAL;
+    }
+  } else {
+    if (p.mul.bn_mean != nullptr) { vfd_set_error("conv: the BatchNorm hand-over is bf16 only"); return VFD_EINVAL; }
+  }
   const int variant = p.variant;   // tuning override (env VFD_IGEMM_VARIANT); 0 = heuristic below
   if (p.Cout > 64) {
     // measured on the ganomaly pyramid (tools/layer_bench.py, bf16): 256c x 128p (8 waves) 750-825 TFLOP/s for
@@ -519,7 +528,7 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
 
 static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
                          size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream,
-                         const void* mul_src = nullptr, int mul_act = 0, float mul_slope = 0.f) {
+                         const MulP& mul = no_mul()) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
   vfd_conv_desc dn = *d_in;
   if (dn.transposed) {
@@ -541,7 +550,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   }
   {
     // thin-channel pyramid ends have their own kernels (conv_small.hip); they need no workspace
-    const int h = mul_src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats, ws_query != nullptr, as_stream(stream));
+    const int h = mul.src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
     if (h > 0) {
       if (ws_query != nullptr) *ws_query = 0;
@@ -549,7 +558,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
     }
   }
   {
-    const int h = vfd_conv_halo_try(d, x, packed, bias, y, stats, mul_src, mul_act, mul_slope, ws_query != nullptr, as_stream(stream));
+    const int h = vfd_conv_halo_try(d, x, packed, bias, y, stats, mul, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
     if (h > 0) {
       if (ws_query != nullptr) *ws_query = 0;
@@ -566,7 +575,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   p.Kw = d->kd * d->kh * d->kw * p.Cip;
   p.act = d->act; p.slope = d->slope;
   p.ksplit = 1; p.ws = reinterpret_cast<float*>(ws);
-  p.mul_src = mul_src; p.mul_act = mul_act; p.mul_slope = mul_slope;
+  p.mul = mul;
   {
     const int kk[3] = {p.kd, p.kh, p.kw}, ss[3] = {p.sd, p.sh, p.sw}, pp[3] = {p.pd, p.ph, p.pw}, oo[3] = {p.Do, p.Ho, p.Wo};
     p.dim_tab = 1;
@@ -609,7 +618,7 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
     snprintf(buf, n, "%s<%s>", cpad(dn.Cin) == 8 ? "conv_cin8" : "convt_thin", t);
     return VFD_OK;
   }
-  if (vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, true, nullptr) > 0) {
+  if (vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, no_mul(), true, nullptr) > 0) {
     snprintf(buf, n, "conv_halo<%s,%s>", t, dn.Cout > 32 ? "64c_x_256p" : "32c_x_256p");
     return VFD_OK;
   }
@@ -635,7 +644,30 @@ extern "C" int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const
                                     const void* mul_src, int mul_act, float mul_slope, void* stream) {
   VFD_REQUIRE(mul_src != nullptr && ((uintptr_t)mul_src & 15) == 0, "conv_forward_mul: mul_src must be a 16-byte aligned tensor of y's shape");
   VFD_REQUIRE(mul_act >= VFD_ACT_NONE && mul_act <= VFD_ACT_TANH, "conv_forward_mul: bad activation %d", mul_act);
-  return conv_dispatch(d, x, packed, bias, y, nullptr, 0, nullptr, 0, nullptr, stream, mul_src, mul_act, mul_slope);
+  MulP m = no_mul();
+  m.src = mul_src; m.act = mul_act; m.slope = mul_slope;
+  return conv_dispatch(d, x, packed, bias, y, nullptr, 0, nullptr, 0, nullptr, stream, m);
+}
+
+// the BatchNorm hand-over needs the row-store epilogue (conv_epilogue.hpp, VIA_LDS): bf16 tiles of >= 64 channels, which
+// is what every dispatch path (conv_halo, conv_igemm) picks for more than 32 output channels
+extern "C" int vfd_conv_bn_backward_supported(const vfd_conv_desc* d) {
+  return d != nullptr && d->dtype == VFD_BF16 && d->Cout > 32;
+}
+
+extern "C" int vfd_conv_forward_bn_backward(const vfd_conv_desc* d, const void* x, const void* packed, void* y, const void* bn_x,
+                                            const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                            float slope, float* sums, size_t sums_bytes, void* stream) {
+  VFD_REQUIRE(d != nullptr && vfd_conv_bn_backward_supported(d), "conv_forward_bn_backward: needs bf16 and more than 32 output channels");
+  VFD_REQUIRE(bn_x != nullptr && ((uintptr_t)bn_x & 15) == 0 && mean && rstd && sums, "conv_forward_bn_backward: bad arguments");
+  VFD_REQUIRE(sums_bytes >= (size_t)VFD_STATS_REPLICAS * 2 * cpad(d->Cout) * sizeof(float),
+              "conv_forward_bn_backward: sums buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) floats", sums_bytes);
+  VFD_REQUIRE(act >= VFD_ACT_NONE && act <= VFD_ACT_TANH, "conv_forward_bn_backward: bad activation %d", act);
+  VFD_REQUIRE(d->act == VFD_ACT_NONE, "conv_forward_bn_backward: the data-gradient convolution itself has no activation");
+  MulP m = no_mul();
+  m.src = bn_x; m.act = act; m.slope = slope;
+  m.bn_mean = mean; m.bn_rstd = rstd; m.bn_gamma = gamma; m.bn_beta = beta; m.bn_sums = sums;
+  return conv_dispatch(d, x, packed, nullptr, y, nullptr, 0, nullptr, 0, nullptr, stream, m);
 }
 
 // Tuning aid (not part of the public ABI): resident workgroups per CU the runtime grants the main kernels.

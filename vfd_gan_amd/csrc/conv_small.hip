@@ -235,9 +235,11 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
       }
     }
     const long long mw = (long long)tile * CIN8_TILE + wave * (CIN8_NJ * 16);
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));      // keeps the 8 read addresses below from being hoisted out of the tile loop (3 spills)
 #pragma unroll
     for (int it = 0; it < CIN8_NJ * 2; ++it) {
-      const int px = it * 8 + (lane >> 3), c = lane & 7, n = px & 15;
+      const int px = it * 8 + (lane_o >> 3), c = lane_o & 7, n = px & 15;
       uint4 v = *reinterpret_cast<const uint4*>(ot + px * 128 + ((c ^ (n >> 1)) << 4));
       if (n & 1) v = make_uint4(v.z, v.w, v.x, v.y);
       if (mw + px < p.M && c * 8 < p.Cop)
@@ -248,7 +250,8 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
     __syncthreads();
     if (tid < 2 * 16 * NI_) {
       const int which = tid / (16 * NI_), c = tid - which * (16 * NI_);
-      if (c < p.Cout) atomicAdd(p.stats + (size_t)(blockIdx.x % VFD_STATS_REPLICAS) * 2 * p.Cop + which * p.Cop + c, red_s[tid]);
+      float* rep = p.stats + (blockIdx.x % VFD_STATS_REPLICAS) * 2 * p.Cop;      // 32-bit offsets: the buffer is a few KB
+      if (c < p.Cout) atomicAdd(rep + which * p.Cop + c, red_s[tid]);
     }
   }
 }

@@ -35,7 +35,7 @@ def cpad(c):
     return (c + 7) & ~7
 
 
-STATS_REPLICAS = 64  # == VFD_STATS_REPLICAS (include/vfdgan_hip.h)
+STATS_REPLICAS = 8  # == VFD_STATS_REPLICAS (include/vfdgan_hip.h); 64 measured no faster (atomic contention is not a cost)
 
 # Debug switch (env VFD_POISON_WS=1 or set_workspace_poison): every kernel workspace (split-K slabs of the filter
 # gradient and of few-pixel convolutions, BatchNorm / bias / loss partials) is filled with NaN bit patterns before
@@ -75,13 +75,14 @@ class ClTensor:
     ``C``   logical channels (pad channels t[..., C:] are zero)
     ``nsp`` spatial rank seen by the user: 3 -> (N,C,D,H,W), 2 -> (N,C,H,W), 0 -> (N,C)
     """
-    __slots__ = ("t", "C", "nsp", "fused_act")
+    __slots__ = ("t", "C", "nsp", "fused_act", "fused_bn")
 
     def __init__(self, t, C, nsp, fused_act=None):
         self.t, self.C, self.nsp = t, C, nsp
         # set by conv(): this block is the output of a conv with a fused activation; a sole consumer may claim the
         # activation's gradient into its own data-gradient epilogue (see _Conv)
         self.fused_act = fused_act
+        self.fused_bn = None      # hand-over token of the BatchNorm(+activation) that produced t (see _BnAct)
 
     @property
     def shape(self):
@@ -353,14 +354,22 @@ def _conv_flops(desc):
     return 2.0 * px * taps * desc.Cin * desc.Cout
 
 
-def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None):
-    """`mul` = (tensor of out's shape, act, slope): out *= act'(tensor) in the epilogue (vfd_conv_forward_mul)."""
+def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None, bn=None):
+    """`mul` = (tensor of out's shape, act, slope): out *= act'(tensor) in the epilogue (vfd_conv_forward_mul).
+    `bn` = hand-over token of a BatchNorm+activation producer (_BnAct): out = g and the sums of g, g*xhat go to the token's
+    buffer (vfd_conv_forward_bn_backward)."""
     timer = _TIMER[0]
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     lib = load()
-    if mul is not None:
+    if bn is not None:
+        assert stats is None and mul is None and bias is None and tuple(bn["x"].shape) == tuple(out.shape) and bn["x"].dtype == out.dtype
+        check(lib.vfd_conv_forward_bn_backward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), out.data_ptr(), bn["x"].data_ptr(),
+                                               bn["mean"].data_ptr(), bn["rstd"].data_ptr(), ptr(bn["gamma"]), ptr(bn["beta"]),
+                                               int(bn["act"]), float(bn["slope"]), bn["sums"].data_ptr(), bn["sums"].numel() * 4,
+                                               stream()), "conv_forward_bn_backward")
+    elif mul is not None:
         assert stats is None and tuple(mul[0].shape) == tuple(out.shape) and mul[0].dtype == out.dtype
         check(lib.vfd_conv_forward_mul(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
                                        mul[0].data_ptr(), int(mul[1]), float(mul[2]), stream()), "conv_forward_mul")
@@ -402,9 +411,18 @@ class _Conv(torch.autograd.Function):
         # `in_act` is the token of the conv+activation that produced x; claiming it means THIS layer's data gradient is
         # delivered already multiplied by act'(x) (vfd_conv_forward_mul) and the producer skips its act_backward pass.
         ctx.in_act = None
+        ctx.in_bn = None
         if in_act is not None and ctx.needs_input_grad[0]:
-            in_act["claimed"] = True
-            ctx.in_act = (in_act["act"], in_act["slope"])
+            if "sums" in in_act:
+                # BatchNorm(+activation) producer: this layer's data gradient also carries BatchNorm's backward reduce
+                # (vfd_conv_forward_bn_backward), where the data-gradient kernel has the row-store epilogue
+                ddesc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
+                if load().vfd_conv_bn_backward_supported(ctypes.byref(ddesc)):
+                    in_act["claimed"] = True
+                    ctx.in_bn = in_act
+            else:
+                in_act["claimed"] = True
+                ctx.in_act = (in_act["act"], in_act["slope"])
         ctx.out_act = out_act
         ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
         return out
@@ -433,7 +451,7 @@ class _Conv(torch.autograd.Function):
             packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
             gx = torch.empty_like(x)
             desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
-            _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None)
+            _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
         if ctx.needs_input_grad[1]:
             desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
@@ -498,7 +516,7 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
     if min(out_dhw) <= 0:
         raise RuntimeError("conv: kernel %s does not fit input %s (padding %s)" % (k, in_dhw, p))
     geom = (Cin, Cout, k, s, p, out_dhw, bool(transposed), act, float(slope))
-    in_act = x.fused_act if claim_act_grad else None
+    in_act = (x.fused_act or x.fused_bn) if claim_act_grad else None
     out_act = {"claimed": False, "act": act, "slope": float(slope)} if act != _lib.ACT_NONE else None
     out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act)
     return ClTensor(out, Cout, nsp, out_act)
@@ -509,7 +527,7 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
 # ---------------------------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt):
+    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, token):
         lib = load()
         x = x.contiguous()
         rows = x.numel() // x.shape[-1]
@@ -517,20 +535,26 @@ class _BnAct(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         dtc = dtype_code(x.dtype)
+        y = torch.empty_like(x)
+        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         if sums is not None:
+            # statistics handed over by the producing conv's epilogue: fold + normalise + activate in one launch
             if sums.numel() < STATS_REPLICAS * 2 * cpad(C):
                 raise RuntimeError("bn_act: statistics buffer too small (use functional.new_stats_buffer)")
-            check(lib.vfd_bn_stats_from_sums(sums.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
-                                             ptr(running_mean), ptr(running_var), ptr(nbt), stream()), "bn_stats_from_sums")
+            check(lib.vfd_bn_act_forward_sums(dtc, x.data_ptr(), y.data_ptr(), rows, C, sums.data_ptr(), eps, momentum,
+                                              mean.data_ptr(), rstd.data_ptr(), ptr(running_mean), ptr(running_var), ptr(nbt),
+                                              ptr(g_), ptr(b_), act, slope, stream()), "bn_act_forward_sums")
         else:
             ws = _workspace(lib.vfd_bn_workspace(rows, C), dev)
             check(lib.vfd_bn_stats(dtc, x.data_ptr(), rows, C, eps, momentum, mean.data_ptr(), rstd.data_ptr(),
                                    ptr(running_mean), ptr(running_var), ptr(nbt), ws.data_ptr(), stream()), "bn_stats")
-        y = torch.empty_like(x)
-        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
-        check(lib.vfd_bn_act_forward(dtc, x.data_ptr(), y.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), ptr(g_),
-                                     ptr(b_), act, slope, stream()), "bn_act_forward")
+            check(lib.vfd_bn_act_forward(dtc, x.data_ptr(), y.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), ptr(g_),
+                                         ptr(b_), act, slope, stream()), "bn_act_forward")
         ctx.meta = (rows, C, act, slope)
+        ctx.token = token
+        if token is not None:
+            # what the consumer conv's data-gradient epilogue needs to take over the reduce pass of this backward
+            token.update(x=x, mean=mean, rstd=rstd, gamma=g_, beta=b_, act=act, slope=slope, claimed=False)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
 
@@ -548,23 +572,36 @@ class _BnAct(torch.autograd.Function):
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
         db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
+        nret = (None,) * 10
+        if ctx.token is not None and ctx.token["claimed"]:
+            # gy is already g = dy * act'(z) and the sums of g, g*xhat sit in the token's buffer (written by the consumer's
+            # data gradient): only the apply pass is left
+            check(lib.vfd_bn_backward_apply_sums(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
+                                                 mean.data_ptr(), rstd.data_ptr(), ptr(g_), ctx.token["sums"].data_ptr(),
+                                                 dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), stream()),
+                  "bn_backward_apply_sums")
+            return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
+                    dbeta if (beta is not None and db_acc is None) else None) + nret
         check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                       mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
                                       dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ws.data_ptr(), stream()), "bn_act_backward")
         return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
-                dbeta if (beta is not None and db_acc is None) else None, None, None, None, None, None, None, None, None, None)
+                dbeta if (beta is not None and db_acc is None) else None) + nret
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,
-           sums=None, num_batches_tracked=None):
+           sums=None, num_batches_tracked=None, bwd_sums=None):
     """Training-mode batch normalisation over all rows of `x` followed by `act`; updates the running statistics
     in place (momentum rule, unbiased variance) exactly like torch.nn.BatchNormNd.train(); `num_batches_tracked`
     (int64 device scalar) is incremented by the statistics kernel."""
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise TypeError("num_batches_tracked must be an int64 device tensor")
+    token = {"sums": bwd_sums} if bwd_sums is not None else None
     y = _BnAct.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act),
-                     float(slope), sums, num_batches_tracked)
-    return ClTensor(y, x.C, x.nsp)
+                     float(slope), sums, num_batches_tracked, token)
+    out = ClTensor(y, x.C, x.nsp)
+    out.fused_bn = token      # `bwd_sums`: zeroed [STATS_REPLICAS][2][CPAD(C)] buffer; y must have exactly ONE consumer conv
+    return out
 
 
 def bn_act_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, act=_lib.ACT_NONE, slope=0.0):

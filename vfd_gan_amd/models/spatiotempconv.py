@@ -37,12 +37,12 @@ class SpatioTemporalConv(tnn.Module):
                                         stride=temporal_stride, padding=temporal_padding, bias=bias)
 
     def forward(self, x, stats=None):
-        """spatial conv -> BatchNorm+ReLU (one fused pass; bf16: statistics from the conv epilogue) -> temporal conv.
+        """spatial conv -> BatchNorm+ReLU (one fused pass; bf16: statistics from the conv epilogue) -> temporal conv (bf16: its
+        data gradient carries the BatchNorm+ReLU backward reduce, nn.run_fused).
         `stats` (optional [2*Cp] float32 zeros) receives the temporal conv's per-channel sum / sum of squares for the
         BatchNorm the callers apply next (models/mygannet.py:24-26,113-115)."""
         plain = not isinstance(x, ClTensor)
         if plain:
             x = F.to_cl(x)
-        x = hnn.run_fused([self.spatial_conv, self.bn, self.relu], x)
-        x = self.temporal_conv(x, stats=stats)
+        x = hnn.run_fused([self.spatial_conv, self.bn, self.relu, self.temporal_conv], x, last_stats=stats)
         return x.to_torch() if plain else x

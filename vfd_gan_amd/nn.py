@@ -90,7 +90,7 @@ class Linear(tnn.Linear):
 
 # ---- normalisation ---------------------------------------------------------------------------------------------
 class _BatchNormMixin:
-    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, sums=None):
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, sums=None, bwd_sums=None):
         _need_cl(x, type(self).__name__)
         if x.C != self.num_features:
             raise RuntimeError("BatchNorm: %d channels, expected %d" % (x.C, self.num_features))
@@ -103,7 +103,7 @@ class _BatchNormMixin:
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         nbt = self.num_batches_tracked if self.track_running_stats else None      # += 1 inside the statistics kernel
-        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt)
+        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums)
 
 
 class BatchNorm3d(_BatchNormMixin, tnn.BatchNorm3d):
@@ -176,56 +176,83 @@ _BNS = (BatchNorm3d, BatchNorm2d, BatchNorm1d)
 _NO_HANDOVER = bool(os.environ.get("VFD_NO_ACT_HANDOVER"))    # tuning / bisecting switch
 
 
-def run_fused(mods, x):
+def run_fused(mods, x, last_stats=None):
     """Run a list of HIP-backed layers, fusing conv->act into the conv epilogue, BatchNorm->act into one
-    normalise+activate pass, and (bf16) conv->BatchNorm statistics into the conv epilogue."""
+    normalise+activate pass, (bf16) conv->BatchNorm statistics into the conv epilogue, and the activation / BatchNorm
+    backward of a producer into the data-gradient epilogue of the conv that consumes it.  `last_stats`: statistics buffer
+    for the list's LAST layer (a conv whose BatchNorm the caller applies itself)."""
     i, n = 0, len(mods)
-    fresh_act = False      # x is the (single-consumer) output of a conv with a fused activation of this list
-    # one zero-filled allocation for the statistics buffers of every conv -> BatchNorm pair of the list (one fill
-    # launch instead of one per pair)
+    fresh = False      # x is the (single-consumer) output of a conv+activation or BatchNorm(+activation) of this list
+    epi = use_epilogue_stats(x)
+    handover = epi and not _NO_HANDOVER
+
+    def is_conv(j):
+        return j < n and isinstance(mods[j], _CONVS) and not isinstance(mods[j], Linear)
+
+    def bn_span(j):
+        """BatchNorm at j (training) -> index of the layer after BatchNorm(+activation)."""
+        return j + 2 if (j + 1 < n and _act_of(mods[j + 1]) is not None) else j + 1
+
+    # one zero-filled allocation for every sum buffer of the list (one fill launch): forward statistics of each
+    # conv -> BatchNorm pair, backward sums of each BatchNorm(+activation) -> conv pair
     pool, pool_off = None, 0
-    if use_epilogue_stats(x):
-        need = sum(F.stats_buffer_numel(m.out_channels) for j, m in enumerate(mods[:-1])
-                   if isinstance(m, _CONVS) and not isinstance(m, Linear) and isinstance(mods[j + 1], _BNS) and mods[j + 1].training)
+    if epi:
+        need = 0
+        for j, m in enumerate(mods):
+            if isinstance(m, _BNS) and m.training:
+                if j > 0 and is_conv(j - 1):
+                    need += F.stats_buffer_numel(m.num_features)
+                if handover and is_conv(bn_span(j)):
+                    need += F.stats_buffer_numel(m.num_features)
         if need:
             pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
+
+    def take(C):
+        nonlocal pool_off
+        k = F.stats_buffer_numel(C)
+        buf = pool.narrow(0, pool_off, k)
+        pool_off += k
+        return buf
+
+    def run_bn(j, x, sums):
+        """BatchNorm at j with the activation that follows it; returns (x, next index, x has a hand-over token)."""
+        bn = mods[j]
+        nxt_i = bn_span(j)
+        a = _act_of(mods[j + 1]) if nxt_i == j + 2 else None
+        kw = {"act": a[0], "slope": a[1]} if a is not None else {}
+        give = handover and bn.training and pool is not None and is_conv(nxt_i)
+        if give:
+            kw["bwd_sums"] = take(bn.num_features)
+        return bn(x, sums=sums, **kw) if sums is not None else bn(x, **kw), nxt_i, give
+
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
         if isinstance(m, _CONVS):
-            # x straight out of the previous conv+activation of THIS list has no other consumer: this conv's data
-            # gradient takes that activation's gradient into its epilogue (functional._Conv)
-            kw = {"claim_act_grad": True} if (fresh_act and not isinstance(m, Linear) and not _NO_HANDOVER) else {}
-            fresh_act = False
+            # x straight out of the previous conv+activation / BatchNorm of THIS list has no other consumer: this conv's data
+            # gradient takes that producer's backward into its epilogue (functional._Conv)
+            kw = {"claim_act_grad": True} if (fresh and not isinstance(m, Linear) and not _NO_HANDOVER) else {}
+            fresh = False
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
                 x = m(x, act=a[0], slope=a[1], **kw)
-                fresh_act = not isinstance(m, Linear)
+                fresh = not isinstance(m, Linear)
                 i += 2
                 continue
-            if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and use_epilogue_stats(x):
-                k = F.stats_buffer_numel(m.out_channels)
-                sums = pool.narrow(0, pool_off, k)
-                pool_off += k
+            if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and epi:
+                sums = take(m.out_channels)
                 x = m(x, stats=sums, **kw)
-                a = _act_of(mods[i + 2]) if i + 2 < n else None
-                if a is not None:
-                    x = nxt(x, act=a[0], slope=a[1], sums=sums)
-                    i += 3
-                else:
-                    x = nxt(x, sums=sums)
-                    i += 2
+                x, i, fresh = run_bn(i + 1, x, sums)
                 continue
+            if last_stats is not None and i == n - 1:
+                kw["stats"] = last_stats
             x = m(x, **kw)
             i += 1
             continue
-        fresh_act = False
+        fresh = False
         if isinstance(m, _BNS):
-            a = _act_of(nxt) if nxt is not None else None
-            if a is not None:
-                x = m(x, act=a[0], slope=a[1])
-                i += 2
-                continue
+            x, i, fresh = run_bn(i, x, None)
+            continue
         x = m(x)
         i += 1
     return x
