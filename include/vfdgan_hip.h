@@ -120,8 +120,9 @@ int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* pack
  * epilogue stores g = conv(x, packed) * act'(gamma * xh + beta) and adds the per-channel sums of g and of g * xh into
  * sums (float32 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed): BatchNorm's backward reduce pass, without its two
  * reads.  vfd_bn_backward_apply_sums finishes the BatchNorm backward from (g, sums).  bf16 with more than 32 output
- * channels only (vfd_conv_bn_backward_supported); no bias, no activation of its own, no split-K, no workspace. */
-int vfd_conv_bn_backward_supported(const vfd_conv_desc* d);
+ * channels only; no bias, no activation of its own, no split-K, no workspace. */
+int vfd_conv_bn_backward_supported(const vfd_conv_desc* d);   /* possible AND worth it: Cout >= the threshold below */
+int vfd_conv_set_bn_handover_min_channels(int c);              /* default 129 (measured break-even); returns the previous value */
 int vfd_conv_forward_bn_backward(const vfd_conv_desc* d, const void* x, const void* packed, void* y, const void* bn_x,
                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                  float slope, float* sums, size_t sums_bytes, void* stream);
@@ -201,6 +202,13 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
 int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C,
                                const float* mean, const float* rstd, const float* gamma, const float* sums,
                                float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* stream);
+
+/* vfd_bn_act_backward in TWO launches: the reduce pass adds its workgroup partials into `sums` (float32
+ * [VFD_STATS_REPLICAS][2][Cp], pre-zeroed; float atomics) and the apply pass folds them itself.                    */
+int vfd_bn_act_backward_sums(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                             float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
+                             float* dbeta_acc, void* stream);
 
 /* Element-wise activation and its backward from the OUTPUT (all supported activations are invertible in
  * sign / expressible from y): dx = dy * act'(y).                                                          */

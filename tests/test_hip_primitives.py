@@ -241,10 +241,12 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
             mine.load_state_dict(state0)
             mine.to(dev)
             calls = {}
-            names = ("vfd_conv_forward_bn_backward", "vfd_bn_backward_apply_sums", "vfd_bn_act_forward_sums", "vfd_bn_act_backward")
+            names = ("vfd_conv_forward_bn_backward", "vfd_bn_backward_apply_sums", "vfd_bn_act_forward_sums", "vfd_bn_act_backward",
+                     "vfd_bn_act_backward_sums")
             origs = {nm: _count_calls(lib, nm, calls) for nm in names}
             old = vnn._NO_HANDOVER
             vnn._NO_HANDOVER = mode == "unfused"
+            old_minc = lib.vfd_conv_set_bn_handover_min_channels(33)      # default: 129, where the hand-over starts to pay
             try:
                 xd = x.to(dev).requires_grad_()
                 y = mine(F.to_cl(xd, dt)).to_torch()
@@ -252,6 +254,7 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
                 torch.cuda.synchronize()
             finally:
                 vnn._NO_HANDOVER = old
+                lib.vfd_conv_set_bn_handover_min_channels(old_minc)
                 for nm, o in origs.items():
                     setattr(lib, nm, o)
             nbn = sum(isinstance(m, (vnn.BatchNorm2d, vnn.BatchNorm3d)) for m in mine)
@@ -260,9 +263,11 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
                 # every BatchNorm whose consumer's data gradient has more than 32 channels: 64, 136, 264, 40 (frames); 64, 48 (volumes)
                 want = 4 if nd == 2 else 2
                 assert calls.get("vfd_conv_forward_bn_backward", 0) == want and calls.get("vfd_bn_backward_apply_sums", 0) == want, calls
-                assert calls.get("vfd_bn_act_backward", 0) == nbn - want
+                assert calls.get("vfd_bn_act_backward_sums", 0) == nbn - want
             else:
-                assert calls.get("vfd_conv_forward_bn_backward", 0) == 0 and calls.get("vfd_bn_act_backward", 0) == nbn
+                # no hand-over: reduce pass with atomics into the pooled sums + folding apply pass (two launches)
+                assert calls.get("vfd_conv_forward_bn_backward", 0) == 0 and calls.get("vfd_bn_act_backward_sums", 0) == nbn
+            assert calls.get("vfd_bn_act_backward", 0) == 0
             results[mode] = (y, xd.grad, {n: p.grad.clone() for n, p in mine.named_parameters()},
                              {n: b.clone() for n, b in mine.named_buffers()})
     finally:

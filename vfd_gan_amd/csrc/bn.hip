@@ -293,7 +293,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 }
 
 // ---- backward reduce: partial sums of g = dy*act'(z) and g*xhat per channel ---------------------------------------
-template <typename T, int ACT>
+// SUMS: the workgroup's partial sums are added into a replica row of a zeroed [VFD_STATS_REPLICAS][2][Cp] buffer (float
+// atomics, one per channel and workgroup) instead of a slot of the partials workspace: no finalize launch, the apply
+// kernel folds the replicas itself.
+template <typename T, int ACT, bool SUMS>
 __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  float* __restrict__ part, long long rows, int C, int TX,
                                                                  long long rpb, const float* __restrict__ mean,
@@ -350,9 +353,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
     for (int j = 1; j < TY; ++j)
 #pragma unroll
       for (int k = 0; k < 16; ++k) a[k] += sh[j * TX + tx][k];
-    float* dst = part + (size_t)blockIdx.y * 2 * Cp;
+    if constexpr (SUMS) {
+      float* dst = part + (size_t)(blockIdx.y % VFD_STATS_REPLICAS) * 2 * Cp;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dst[g * 8 + k] = a[k]; dst[Cp + g * 8 + k] = a[8 + k]; }
+      for (int k = 0; k < 8; ++k) {
+        if (g * 8 + k < C) { atomicAdd(dst + g * 8 + k, a[k]); atomicAdd(dst + Cp + g * 8 + k, a[8 + k]); }
+      }
+    } else {
+      float* dst = part + (size_t)blockIdx.y * 2 * Cp;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dst[g * 8 + k] = a[k]; dst[Cp + g * 8 + k] = a[8 + k]; }
+    }
   }
 }
 
@@ -431,17 +442,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
 // ---- backward apply for a BatchNorm whose gradient arrives as g = dy * act'(z) with the sums of g and g * xhat in replica
 // rows (written by the consumer convolution's data-gradient epilogue, conv_epilogue.hpp): the reduce pass and the finalize
 // launch are gone; the row-0 workgroups publish dgamma / dbeta.
-template <typename T>
+// ACT < 0: gz IS g (conv hand-over); ACT >= 0: gz is dy and g = dy * act'(gamma * xhat + beta) is formed here, as in
+// bn_act_bwd_apply_kernel (the sums then come from bn_act_bwd_partial_kernel<.., SUMS>).
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restrict__ x, const T* __restrict__ gz, T* __restrict__ dx,
                                                                 long long rows, int C, int TX, long long rpb,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float slope, const float* __restrict__ sums,
                                                                 float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
   if (g >= GR) return;
-  float mu[8], rs[8], gr[8], c1[8], c2[8];
+  float mu[8], rs[8], gr[8], c1[8], c2[8], ga[8], be[8];
   const float inv = 1.f / (float)rows;
   {
     double s1[8], s2[8];
@@ -453,7 +467,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
       const bool ok = c < C;
       const float sg = (float)s1[k], sgx = (float)s2[k];
       mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
-      gr[k] = ok ? (gamma ? gamma[c] : 1.f) * rs[k] : 0.f;
+      ga[k] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
+      be[k] = (ok && beta) ? beta[c] : 0.f;
+      gr[k] = ga[k] * rs[k];
       c1[k] = ok ? sg * inv : 0.f; c2[k] = ok ? sgx * inv : 0.f;
       if (ok && publish) {
         dbeta[c] = sg;
@@ -481,7 +497,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = (v[u][k] - mu[k]) * rs[k];
-        d[u][k] = gr[k] * (d[u][k] - c1[k] - xh * c2[k]);
+        float gzv = d[u][k];
+        if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
+        d[u][k] = gr[k] * (gzv - c1[k] - xh * c2[k]);
       }
       if (ru < rend) store8(dx + ru * Cp + g * 8, d[u]);
     }
@@ -584,10 +602,34 @@ extern "C" int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* 
   const Tiling t = make_stream_tiling(rows, C);
   dim3 grid(t.gx, t.gy);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(bn_bwd_apply_sums_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<bf16_t, -1>), grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_sums_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)g, (float*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<float, -1>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)g, (float*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
   VFD_CHECK_LAUNCH("bn_backward_apply_sums");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_backward_sums(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* mean,
+                                        const float* rstd, const float* gamma, const float* beta, int act, float slope,
+                                        float* sums, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+                                        void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_backward_sums: bad dtype");
+  VFD_REQUIRE(x && dy && dx && mean && rstd && sums && dgamma && dbeta && rows > 0 && C > 0, "bn_act_backward_sums: bad arguments");
+  VFD_REQUIRE(((uintptr_t)sums & 15) == 0, "bn_act_backward_sums: the sums buffer must be 16-byte aligned");
+  static const int pnb = getenv("VFD_BN_PART_BLOCKS") ? atoi(getenv("VFD_BN_PART_BLOCKS")) : 512;
+  const Tiling t = make_tiling(rows, C, pnb < BN_MAX_BLOCKS ? pnb : BN_MAX_BLOCKS);
+  dim3 grid(t.gx, t.gy);
+  hipStream_t st = as_stream(stream);
+#define BN_BWD_PS(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_, true>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)dy, sums, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
+  BN_ACT_DISPATCH(BN_BWD_PS);
+#undef BN_BWD_PS
+  VFD_CHECK_LAUNCH("bn_act_bwd_partial(sums)");
+  const Tiling ta = make_stream_tiling(rows, C);
+  dim3 grid2(ta.gx, ta.gy);
+#define BN_BWD_AS(T_, ACT_) hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<T_, ACT_>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)dy, (T_*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, sums, dgamma, dbeta, dgamma_acc, dbeta_acc)
+  BN_ACT_DISPATCH(BN_BWD_AS);
+#undef BN_BWD_AS
+  VFD_CHECK_LAUNCH("bn_bwd_apply_sums");
   return VFD_OK;
 }
 
@@ -601,7 +643,7 @@ extern "C" int vfd_bn_act_backward(int dtype, const void* x, const void* dy, voi
   dim3 grid(t.gx, t.gy);
   float* part = reinterpret_cast<float*>(ws);
   hipStream_t st = as_stream(stream);
-#define BN_BWD_P(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
+#define BN_BWD_P(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_, false>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)dy, part, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope)
   BN_ACT_DISPATCH(BN_BWD_P);
 #undef BN_BWD_P
   VFD_CHECK_LAUNCH("bn_act_bwd_partial");

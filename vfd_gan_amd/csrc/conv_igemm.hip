@@ -651,14 +651,25 @@ extern "C" int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const
 
 // the BatchNorm hand-over needs the row-store epilogue (conv_epilogue.hpp, VIA_LDS): bf16 tiles of >= 64 channels, which
 // is what every dispatch path (conv_halo, conv_igemm) picks for more than 32 output channels
+// ... and pays from 129 channels on (measured, ganomaly 512 frames: the 256-channel tile's epilogue grows by what the
+// separate reduce pass cost, 30 us, and two launches go; the 128- and 64-channel tiles grow by 78 / 150 us against a
+// 60 / 100 us reduce pass: all workgroups reach their epilogues together, so the extra read is an HBM burst nothing hides)
+static int g_bn_handover_min_c = -1;
+extern "C" int vfd_conv_set_bn_handover_min_channels(int c) {
+  const int prev = g_bn_handover_min_c < 0 ? 129 : g_bn_handover_min_c;
+  g_bn_handover_min_c = c < 33 ? 33 : c;
+  return prev;
+}
 extern "C" int vfd_conv_bn_backward_supported(const vfd_conv_desc* d) {
-  return d != nullptr && d->dtype == VFD_BF16 && d->Cout > 32;
+  if (g_bn_handover_min_c < 0) g_bn_handover_min_c = getenv("VFD_BN_HANDOVER_MIN_C") ? atoi(getenv("VFD_BN_HANDOVER_MIN_C")) : 129;
+  if (g_bn_handover_min_c < 33) g_bn_handover_min_c = 33;
+  return d != nullptr && d->dtype == VFD_BF16 && d->Cout >= g_bn_handover_min_c;
 }
 
 extern "C" int vfd_conv_forward_bn_backward(const vfd_conv_desc* d, const void* x, const void* packed, void* y, const void* bn_x,
                                             const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                             float slope, float* sums, size_t sums_bytes, void* stream) {
-  VFD_REQUIRE(d != nullptr && vfd_conv_bn_backward_supported(d), "conv_forward_bn_backward: needs bf16 and more than 32 output channels");
+  VFD_REQUIRE(d != nullptr && d->dtype == VFD_BF16 && d->Cout > 32, "conv_forward_bn_backward: needs bf16 and more than 32 output channels");
   VFD_REQUIRE(bn_x != nullptr && ((uintptr_t)bn_x & 15) == 0 && mean && rstd && sums, "conv_forward_bn_backward: bad arguments");
   VFD_REQUIRE(sums_bytes >= (size_t)VFD_STATS_REPLICAS * 2 * cpad(d->Cout) * sizeof(float),
               "conv_forward_bn_backward: sums buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) floats", sums_bytes);

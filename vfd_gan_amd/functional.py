@@ -582,6 +582,14 @@ class _BnAct(torch.autograd.Function):
                   "bn_backward_apply_sums")
             return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
                     dbeta if (beta is not None and db_acc is None) else None) + nret
+        if ctx.token is not None:
+            # unclaimed, but a zeroed sums buffer is at hand: reduce into it with atomics, fold in the apply pass (two launches)
+            check(lib.vfd_bn_act_backward_sums(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
+                                               mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope,
+                                               ctx.token["sums"].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc),
+                                               ptr(db_acc), stream()), "bn_act_backward_sums")
+            return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
+                    dbeta if (beta is not None and db_acc is None) else None) + nret
         check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                       mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
                                       dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ws.data_ptr(), stream()), "bn_act_backward")

@@ -28,9 +28,10 @@ def _conv_bn_act(block, x, slope):
     """SpatioTemporalConv -> BatchNorm3d -> LeakyReLU(slope) with the BatchNorm statistics taken from the temporal
     conv's epilogue (bf16) and normalise+activate in one pass."""
     if block.bn.training and hnn.use_epilogue_stats(x):
-        sums = F.new_stats_buffer(block.bn.num_features, x.t.device)
-        x = block.conv(x, stats=sums)
-        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=sums)
+        k = F.stats_buffer_numel(block.bn.num_features)
+        buf = torch.zeros(2 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums: one fill
+        x = block.conv(x, stats=buf[:k])
+        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:])
     x = block.conv(x)
     return block.bn(x, act=_lib.ACT_LRELU, slope=slope)
 

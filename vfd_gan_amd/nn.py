@@ -194,7 +194,7 @@ def run_fused(mods, x, last_stats=None):
         return j + 2 if (j + 1 < n and _act_of(mods[j + 1]) is not None) else j + 1
 
     # one zero-filled allocation for every sum buffer of the list (one fill launch): forward statistics of each
-    # conv -> BatchNorm pair, backward sums of each BatchNorm(+activation) -> conv pair
+    # conv -> BatchNorm pair, backward sums of each BatchNorm
     pool, pool_off = None, 0
     if epi:
         need = 0
@@ -202,8 +202,7 @@ def run_fused(mods, x, last_stats=None):
             if isinstance(m, _BNS) and m.training:
                 if j > 0 and is_conv(j - 1):
                     need += F.stats_buffer_numel(m.num_features)
-                if handover and is_conv(bn_span(j)):
-                    need += F.stats_buffer_numel(m.num_features)
+                need += F.stats_buffer_numel(m.num_features)      # backward sums (every training BatchNorm)
         if need:
             pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
 
@@ -220,9 +219,9 @@ def run_fused(mods, x, last_stats=None):
         nxt_i = bn_span(j)
         a = _act_of(mods[j + 1]) if nxt_i == j + 2 else None
         kw = {"act": a[0], "slope": a[1]} if a is not None else {}
-        give = handover and bn.training and pool is not None and is_conv(nxt_i)
-        if give:
-            kw["bwd_sums"] = take(bn.num_features)
+        if bn.training and pool is not None:
+            kw["bwd_sums"] = take(bn.num_features)      # backward: reduce with atomics + folding apply, or the conv hand-over
+        give = handover and "bwd_sums" in kw and is_conv(nxt_i)
         return bn(x, sums=sums, **kw) if sums is not None else bn(x, **kw), nxt_i, give
 
     while i < n:
