@@ -93,6 +93,12 @@ typedef struct vfd_conv_desc {
 int vfd_pack_filter(int dtype, const float* w, void* packed, int A, int B, int T, int transpose_ab,
                     void* stream);
 
+/* Many vfd_pack_filter jobs in one launch (all filter copies of one optimiser, right after its step).  jobs_dev: device
+ * array of njobs x 8 int64 {w, packed, A, B, T, transpose_ab, dtype, first_block}; first_block = running sum of
+ * vfd_pack_filter_blocks() over the preceding jobs, total_blocks the sum over all.                                   */
+int64_t vfd_pack_filter_blocks(int A, int B, int T, int transpose_ab);
+int vfd_pack_filters(const int64_t* jobs_dev, int njobs, int64_t total_blocks, void* stream);
+
 /* y = act(conv(x, packed) + bias).  `bias` float32[Cout] or NULL.
  * When stats != NULL (float32 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates
  * the per-channel sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
@@ -198,17 +204,21 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
 
 /* The apply pass alone, for a gradient that arrives as g = dy*act'(.) with sums[VFD_STATS_REPLICAS][2][Cp] = the
  * per-channel sums of g and g*xhat (vfd_conv_forward_bn_backward): dgamma/dbeta are published by the first row of
- * workgroups (OVERWRITTEN; *_acc ACCUMULATED into), dx as above.  One launch instead of three.                  */
+ * workgroups (OVERWRITTEN; *_acc ACCUMULATED into), dx as above.  One launch instead of three.
+ * colsum_acc (NULL or float32[C], ACCUMULATED into with float atomics): the per-channel sums of dx, i.e. the bias
+ * gradient of the convolution that feeds this BatchNorm (nn.Conv3d(bias=True) -> BatchNorm3d, models/anogan.py:44-70)
+ * without vfd_bias_grad's own pass over dx.                                                                       */
 int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C,
                                const float* mean, const float* rstd, const float* gamma, const float* sums,
-                               float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* stream);
+                               float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* colsum_acc,
+                               void* stream);
 
 /* vfd_bn_act_backward in TWO launches: the reduce pass adds its workgroup partials into `sums` (float32
  * [VFD_STATS_REPLICAS][2][Cp], pre-zeroed; float atomics) and the apply pass folds them itself.                    */
 int vfd_bn_act_backward_sums(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C,
                              const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                              float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
-                             float* dbeta_acc, void* stream);
+                             float* dbeta_acc, float* colsum_acc, void* stream);
 
 /* Element-wise activation and its backward from the OUTPUT (all supported activations are invertible in
  * sign / expressible from y): dx = dy * act'(y).                                                          */

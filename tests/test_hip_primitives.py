@@ -207,7 +207,7 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
     if nd == 2:
         T, V = torch.nn, vnn
         spec = lambda M: [M.Conv2d(5, 64, 4, 2, 1, bias=False), M.BatchNorm2d(64), M.LeakyReLU(0.2),      # noqa: E731
-                          M.Conv2d(64, 136, 3, 1, 1, bias=False), M.BatchNorm2d(136), M.ReLU(),
+                          M.Conv2d(64, 136, 3, 1, 1, bias=True), M.BatchNorm2d(136), M.ReLU(),
                           M.Conv2d(136, 264, 4, 2, 1, bias=False), M.BatchNorm2d(264), M.LeakyReLU(0.2),
                           M.ConvTranspose2d(264, 40, 4, 2, 1, bias=False), M.BatchNorm2d(40),
                           M.Conv2d(40, 8, 3, 1, 1)]
@@ -215,7 +215,7 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
     else:
         T, V = torch.nn, vnn
         spec = lambda M: [M.Conv3d(40, 64, 3, 1, 1, bias=False), M.BatchNorm3d(64), M.LeakyReLU(0.2),      # noqa: E731
-                          M.Conv3d(64, 48, 3, 1, 1, bias=False), M.BatchNorm3d(48), M.ReLU(),
+                          M.Conv3d(64, 48, 3, 1, 1, bias=True), M.BatchNorm3d(48), M.ReLU(),
                           M.Conv3d(48, 8, (1, 3, 3), 1, (0, 1, 1))]
         x = _rand((2, 40, 4, 12, 12), 32)
     ref = torch.nn.Sequential(*spec(T))
@@ -289,6 +289,11 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
         for n, v in report[mode].items():
             if n.endswith(("running_mean", "running_var", "num_batches_tracked")):
                 assert v[0] < 2e-3, (mode, n, v)
+            elif n == "3.bias":
+                # bias of a conv that feeds a BatchNorm: its gradient (column sums of the BatchNorm's dx, taken inside the
+                # apply pass) is zero up to rounding, in torch as here: bound it against the layer's weight gradient
+                gb, gw = results[mode][2]["3.bias"], results[mode][2]["3.weight"]
+                assert float(gb.abs().max()) < 2e-2 * float(gw.abs().max()), (mode, float(gb.abs().max()), float(gw.abs().max()))
             elif n != "y":
                 assert v[1] < 0.08, (mode, n, v)
                 assert abs(v[1] - report["unfused"][n][1]) < 5e-3, (mode, n, v, report["unfused"][n])
@@ -296,7 +301,8 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
     assert torch.equal(results["fused"][0], results["unfused"][0])
     assert relerr(results["fused"][1], results["unfused"][1]) < 1.5e-2
     for n in results["fused"][2]:
-        assert relerr(results["fused"][2][n], results["unfused"][2][n]) < 1.5e-2, n
+        if n != "3.bias":
+            assert relerr(results["fused"][2][n], results["unfused"][2][n]) < 1.5e-2, n
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])

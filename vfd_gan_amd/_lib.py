@@ -35,6 +35,8 @@ SIGNATURES = {
     "vfd_unflatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_flatten": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_i64, c_vp]),
     "vfd_pack_filter": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "vfd_pack_filter_blocks": (c_i64, [c_int, c_int, c_int, c_int]),
+    "vfd_pack_filters": (c_int, [c_vp, c_int, c_i64, c_vp]),
     "vfd_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp, c_sz, c_vp]),
     "vfd_conv_bn_backward_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "vfd_conv_set_bn_handover_min_channels": (c_int, [c_int]),
@@ -58,9 +60,10 @@ SIGNATURES = {
     "vfd_bn_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_bn_act_forward_sums": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_int, c_f32, c_vp]),
-    "vfd_bn_backward_apply_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vfd_bn_backward_apply_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp]),
     "vfd_bn_act_backward_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_vp,
-                                         c_vp, c_vp, c_vp]),
+                                         c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp]),

@@ -450,12 +450,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float slope, const float* __restrict__ sums,
-                                                                float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc) {
+                                                                float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
+                                                                float* colsum_acc) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
-  if (g >= GR) return;
-  float mu[8], rs[8], gr[8], c1[8], c2[8], ga[8], be[8];
+  __shared__ float sh_cs[256][8 + 1];
+  if (g >= GR) {
+    if (colsum_acc != nullptr) __syncthreads();      // matches the barrier of the column-sum fold at the end
+    return;
+  }
+  float mu[8], rs[8], gr[8], c1[8], c2[8], ga[8], be[8], cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
   const float inv = 1.f / (float)rows;
   {
     double s1[8], s2[8];
@@ -501,7 +508,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
         if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
         d[u][k] = gr[k] * (gzv - c1[k] - xh * c2[k]);
       }
-      if (ru < rend) store8(dx + ru * Cp + g * 8, d[u]);
+      if (ru < rend) {
+        store8(dx + ru * Cp + g * 8, d[u]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] += d[u][k];
+      }
+    }
+  }
+  // bias gradient of the convolution that feeds this BatchNorm: the column sums of dx, folded over the row-lanes and
+  // added to the parameter's gradient (one float atomic per channel and workgroup) — the separate column-sum pass over dx
+  // (vfd_bias_grad: one more read of the tensor and two launches) is gone
+  if (colsum_acc != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh_cs[threadIdx.x][k] = cs[k];
+    __syncthreads();
+    if (ty == 0) {
+      for (int j = 1; j < TY; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] += sh_cs[j * TX + tx][k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (g * 8 + k < C) atomicAdd(colsum_acc + g * 8 + k, cs[k]);
     }
   }
 }
@@ -595,16 +622,16 @@ extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_
 
 extern "C" int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C, const float* mean,
                                           const float* rstd, const float* gamma, const float* sums, float* dgamma, float* dbeta,
-                                          float* dgamma_acc, float* dbeta_acc, void* stream) {
+                                          float* dgamma_acc, float* dbeta_acc, float* colsum_acc, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_backward_apply_sums: bad dtype");
   VFD_REQUIRE(x && g && dx && mean && rstd && sums && dgamma && dbeta && rows > 0 && C > 0, "bn_backward_apply_sums: bad arguments");
   VFD_REQUIRE(((uintptr_t)sums & 15) == 0, "bn_backward_apply_sums: the sums buffer must be 16-byte aligned");
   const Tiling t = make_stream_tiling(rows, C);
   dim3 grid(t.gx, t.gy);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<bf16_t, -1>), grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<bf16_t, -1>), grid, dim3(256), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc, colsum_acc);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<float, -1>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)g, (float*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc);
+    hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<float, -1>), grid, dim3(256), 0, as_stream(stream), (const float*)x, (const float*)g, (float*)dx, (long long)rows, C, t.TX, t.rows_per_block, mean, rstd, gamma, nullptr, 0.f, sums, dgamma, dbeta, dgamma_acc, dbeta_acc, colsum_acc);
   VFD_CHECK_LAUNCH("bn_backward_apply_sums");
   return VFD_OK;
 }
@@ -612,7 +639,7 @@ extern "C" int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* 
 extern "C" int vfd_bn_act_backward_sums(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* mean,
                                         const float* rstd, const float* gamma, const float* beta, int act, float slope,
                                         float* sums, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
-                                        void* stream) {
+                                        float* colsum_acc, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_backward_sums: bad dtype");
   VFD_REQUIRE(x && dy && dx && mean && rstd && sums && dgamma && dbeta && rows > 0 && C > 0, "bn_act_backward_sums: bad arguments");
   VFD_REQUIRE(((uintptr_t)sums & 15) == 0, "bn_act_backward_sums: the sums buffer must be 16-byte aligned");
@@ -626,7 +653,7 @@ extern "C" int vfd_bn_act_backward_sums(int dtype, const void* x, const void* dy
   VFD_CHECK_LAUNCH("bn_act_bwd_partial(sums)");
   const Tiling ta = make_stream_tiling(rows, C);
   dim3 grid2(ta.gx, ta.gy);
-#define BN_BWD_AS(T_, ACT_) hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<T_, ACT_>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)dy, (T_*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, sums, dgamma, dbeta, dgamma_acc, dbeta_acc)
+#define BN_BWD_AS(T_, ACT_) hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<T_, ACT_>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)dy, (T_*)dx, (long long)rows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, sums, dgamma, dbeta, dgamma_acc, dbeta_acc, colsum_acc)
   BN_ACT_DISPATCH(BN_BWD_AS);
 #undef BN_BWD_AS
   VFD_CHECK_LAUNCH("bn_bwd_apply_sums");

@@ -124,6 +124,52 @@ __global__ __launch_bounds__(256) void pack_filter_kernel(const float* __restric
   }
 }
 
+// Every filter copy of one optimiser in ONE launch (after its fused Adam step): jobs[j] = {w, packed, A, B, T, transpose,
+// dtype, first block}, 8 x int64 in device memory; a workgroup finds its job by bisection over the first-block column and
+// does the same 64 x 64 tile as pack_filter_kernel.
+template <typename T>
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, T* __restrict__ out, int A, int B, int Tn, int tr, int r, int c0, int t0,
+                                          float (*tile)[65]) {
+  const int Cc = tr ? A : B, Ccp = (Cc + 7) & ~7;
+  const int nc = min(64, Cc - c0);
+  const int nt = min(64, Tn - t0);
+  for (int i = threadIdx.x; i < 64 * nt; i += 256) {
+    const int c = i / nt, t = i - c * nt;
+    float v = 0.f;
+    if (c < nc) {
+      const int cc = c0 + c;
+      const size_t ab = tr ? (size_t)cc * B + r : (size_t)r * B + cc;
+      v = w[ab * Tn + t0 + t];
+    }
+    tile[c][t] = v;
+  }
+  __syncthreads();
+  const int ncp = min(64, Ccp - c0);
+  for (int i = threadIdx.x; i < 64 * nt; i += 256) {
+    const int t = i >> 6, c = i & 63;
+    if (c < ncp) Elem<T>::st(out + ((size_t)r * Tn + t0 + t) * Ccp + c0 + c, tile[c][t]);
+  }
+}
+__global__ __launch_bounds__(256) void pack_filters_kernel(const long long* __restrict__ jobs, int njobs) {
+  __shared__ float tile[64][65];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {                 // last job whose first block is <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid * 8 + 7] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long long* j = jobs + lo * 8;
+  const int A = (int)j[2], B = (int)j[3], Tn = (int)j[4], tr = (int)j[5];
+  const int Cc = tr ? A : B, ncb = (((Cc + 7) & ~7) + 63) / 64, ntb = (Tn + 63) / 64;
+  long long l = b - j[7];
+  const int tb = (int)(l % ntb); l /= ntb;
+  const int cb = (int)(l % ncb); l /= ncb;
+  const int r = (int)l;
+  if (r >= (tr ? B : A)) return;
+  if (j[6] == VFD_BF16) pack_tile<bf16_t>(reinterpret_cast<const float*>(j[0]), reinterpret_cast<bf16_t*>(j[1]), A, B, Tn, tr, r, cb * 64, tb * 64, tile);
+  else pack_tile<float>(reinterpret_cast<const float*>(j[0]), reinterpret_cast<float*>(j[1]), A, B, Tn, tr, r, cb * 64, tb * 64, tile);
+}
+
 // ---- activation ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int act, float slope) {
@@ -418,6 +464,19 @@ extern "C" int vfd_pack_filter(int dtype, const float* w, void* packed, int A, i
   else
     hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, as_stream(stream), w, (float*)packed, A, B, T, transpose_ab);
   VFD_CHECK_LAUNCH("pack_filter");
+  return VFD_OK;
+}
+
+extern "C" int64_t vfd_pack_filter_blocks(int A, int B, int T, int transpose_ab) {
+  const int R = transpose_ab ? B : A, Cc = transpose_ab ? A : B;
+  return (int64_t)R * ((cpad(Cc) + 63) / 64) * ((T + 63) / 64);
+}
+
+extern "C" int vfd_pack_filters(const int64_t* jobs_dev, int njobs, int64_t total_blocks, void* stream) {
+  VFD_REQUIRE(jobs_dev != nullptr && njobs > 0 && total_blocks > 0 && total_blocks < 0x7fffffffLL, "pack_filters: bad arguments");
+  hipLaunchKernelGGL(pack_filters_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const long long*>(jobs_dev), njobs);
+  VFD_CHECK_LAUNCH("pack_filters");
   return VFD_OK;
 }
 

@@ -7,6 +7,7 @@ wrapped in :class:`ClTensor`, which remembers the logical channel count.  PyTorc
 streams and the autograd tape; no arithmetic of the hot path is done by torch operators.
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -254,27 +255,77 @@ def _triple(v, nsp, fill=1):
     return (fill,) * (3 - len(v)) + v if len(v) < 3 else v
 
 
+_PACK_REGISTRY = {}      # id(optimiser epoch cell) -> {"cell", "entries": [...], "table": device jobs or None, "blocks"}
+
+
 def _packed_filter(weight, dt, transpose_ab, A, B, T):
-    """Cached K-major copy of a filter parameter (see vfd_pack_filter)."""
+    """Cached K-major copy of a filter parameter (see vfd_pack_filter).  The copy's buffer is allocated once and re-packed
+    IN PLACE (a captured graph keeps pointing at it)."""
     cache = weight.__dict__.setdefault("_vfd_packed", {})
     key = (dt, transpose_ab)
     # a parameter owned by vfd_gan_amd.optim.Adam also carries its optimiser's own epoch cell: the fused Adam kernel of
-    # ONE net then invalidates that net's packed copies only (the global epoch re-packed netD's filters after every
-    # netG update too: 42 pack launches per ganomaly step, about half of them for unchanged weights)
+    # ONE net then invalidates that net's packed copies only, and the optimiser re-packs all of them in one launch right
+    # after its step (repack_owned) so that this function hits
     own = getattr(weight, "_vfd_epoch", None)
     tag = (weight._version, _WEIGHT_EPOCH[0], own[0] if own is not None else 0, weight.data_ptr())
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     R, Cc = (B, A) if transpose_ab else (A, B)
-    out = torch.empty((R, T, cpad(Cc)), dtype=dt, device=weight.device)
+    shape = (R, T, cpad(Cc))
     w = weight.detach()
-    if not w.is_contiguous() or w.dtype != torch.float32:
+    direct = w.is_contiguous() and w.dtype == torch.float32
+    if not direct:
         w = w.contiguous().float()
+    if hit is not None and tuple(hit[1].shape) == shape and hit[1].dtype == dt and hit[1].device == weight.device:
+        out = hit[1]
+    else:
+        out = torch.empty(shape, dtype=dt, device=weight.device)
+        hit = None
     check(load().vfd_pack_filter(dtype_code(dt), w.data_ptr(), out.data_ptr(), A, B, T, int(transpose_ab), stream()),
           "pack_filter")
-    cache[key] = (tag, out)
+    entry = [tag, out]
+    cache[key] = entry
+    if own is not None and direct and hit is None:
+        reg = _PACK_REGISTRY.setdefault(id(own), {"cell": own, "entries": [], "table": None, "blocks": 0})
+        reg["entries"] = [e for e in reg["entries"] if not (e[0]() is weight and e[1] == key)]
+        reg["entries"].append((weakref.ref(weight), key, A, B, T, int(transpose_ab), dtype_code(dt)))
+        reg["table"] = None           # rebuilt (one host-to-device copy) at the optimiser's next step
     return out
+
+
+def repack_owned(cell):
+    """Re-pack, in ONE launch, every cached filter copy of the parameters that carry the optimiser epoch cell `cell` (called
+    by vfd_gan_amd.optim.Adam.step right after the update, with the cell already bumped) and mark them fresh."""
+    reg = _PACK_REGISTRY.get(id(cell))
+    if reg is None or not reg["entries"]:
+        return
+    lib = load()
+    live = []
+    for (wref, key, A, B, T, tr, dtc) in reg["entries"]:
+        weight = wref()
+        ent = weight.__dict__.get("_vfd_packed", {}).get(key) if weight is not None else None
+        if ent is not None and getattr(weight, "_vfd_epoch", None) is cell:
+            live.append((weight, key, A, B, T, tr, dtc, ent))
+    if len(live) != len(reg["entries"]):
+        reg["entries"] = [(weakref.ref(e[0]),) + e[1:7] for e in live]
+        reg["table"] = None
+    if not live:
+        return
+    sig = tuple((e[0].data_ptr(), e[7][1].data_ptr()) for e in live)
+    if reg["table"] is None or reg.get("sig") != sig:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the packed-filter table changed during graph capture: run one full eager step first (GraphedStep warmup)")
+        rows, first = [], 0
+        for (weight, key, A, B, T, tr, dtc, ent) in live:
+            rows.append([weight.data_ptr(), ent[1].data_ptr(), A, B, T, tr, dtc, first])
+            first += int(lib.vfd_pack_filter_blocks(A, B, T, tr))
+        reg["table"] = torch.tensor(rows, dtype=torch.int64).to(live[0][0].device)
+        reg["blocks"] = first
+        reg["sig"] = sig
+    check(lib.vfd_pack_filters(reg["table"].data_ptr(), len(live), reg["blocks"], stream()), "pack_filters")
+    for (weight, key, A, B, T, tr, dtc, ent) in live:
+        ent[0] = (weight._version, _WEIGHT_EPOCH[0], cell[0], weight.data_ptr())
 
 
 def _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act=0, slope=0.0):
@@ -390,7 +441,7 @@ class _Conv(torch.autograd.Function):
     gradient through the same kernel with swapped roles + split-K filter gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, stats, in_act, out_act):
+    def forward(ctx, x, weight, bias, geom, stats, in_act, out_act, bias_token=None):
         (Cin, Cout, k, s, p, out_dhw, transposed, act, slope) = geom
         x = x.contiguous()
         N = x.shape[0]
@@ -424,6 +475,7 @@ class _Conv(torch.autograd.Function):
                 in_act["claimed"] = True
                 ctx.in_act = (in_act["act"], in_act["slope"])
         ctx.out_act = out_act
+        ctx.bias_token = bias_token
         ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
         return out
 
@@ -475,7 +527,8 @@ class _Conv(torch.autograd.Function):
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not (ctx.bias_token is not None and ctx.bias_token["taken"]):
+            # (taken: the BatchNorm that consumes this conv's output has already added the column sums of its dx)
             bias = ctx.bias_param
             direct = _direct_grad(bias)
             bws = _workspace(lib.vfd_bias_grad_workspace(Cout), x.device)
@@ -486,11 +539,11 @@ class _Conv(torch.autograd.Function):
                 gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
                 check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, bws.data_ptr(),
                                         stream()), "bias_grad")
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, act=_lib.ACT_NONE, slope=0.0,
-         stats=None, claim_act_grad=False):
+         stats=None, claim_act_grad=False, bias_token=None):
     """Convolution on a ClTensor.  `weight` is the torch-layout float32 parameter ([Cout,Cin,k..] or, transposed,
     [Cin,Cout,k..]); Linear layers pass a [out,in] matrix with x.nsp == 0."""
     nsp = x.nsp
@@ -518,7 +571,7 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
     geom = (Cin, Cout, k, s, p, out_dhw, bool(transposed), act, float(slope))
     in_act = (x.fused_act or x.fused_bn) if claim_act_grad else None
     out_act = {"claimed": False, "act": act, "slope": float(slope)} if act != _lib.ACT_NONE else None
-    out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act)
+    out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act, bias_token)
     return ClTensor(out, Cout, nsp, out_act)
 
 
@@ -527,7 +580,8 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
 # ---------------------------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, token):
+    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, token, conv_bias=None,
+                bias_token=None):
         lib = load()
         x = x.contiguous()
         rows = x.numel() // x.shape[-1]
@@ -552,6 +606,13 @@ class _BnAct(torch.autograd.Function):
                                          ptr(b_), act, slope, stream()), "bn_act_forward")
         ctx.meta = (rows, C, act, slope)
         ctx.token = token
+        ctx.conv_bias = None
+        if (token is not None and bias_token is not None and conv_bias is not None and conv_bias.requires_grad
+                and _direct_grad(conv_bias) is not None):
+            # x is conv(..) + conv_bias: the bias gradient is the column sum of THIS backward's dx, which the apply pass has
+            # in registers; the conv then skips its own column-sum pass over dx
+            bias_token["taken"] = True
+            ctx.conv_bias = conv_bias
         if token is not None:
             # what the consumer conv's data-gradient epilogue needs to take over the reduce pass of this backward
             token.update(x=x, mean=mean, rstd=rstd, gamma=g_, beta=b_, act=act, slope=slope, claimed=False)
@@ -572,13 +633,15 @@ class _BnAct(torch.autograd.Function):
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
         db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
-        nret = (None,) * 10
+        nret = (None,) * 12
+        cs_acc = _direct_grad(ctx.conv_bias) if ctx.conv_bias is not None else None
         if ctx.token is not None and ctx.token["claimed"]:
             # gy is already g = dy * act'(z) and the sums of g, g*xhat sit in the token's buffer (written by the consumer's
             # data gradient): only the apply pass is left
             check(lib.vfd_bn_backward_apply_sums(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                                  mean.data_ptr(), rstd.data_ptr(), ptr(g_), ctx.token["sums"].data_ptr(),
-                                                 dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), stream()),
+                                                 dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ptr(cs_acc),
+                                                 stream()),
                   "bn_backward_apply_sums")
             return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
                     dbeta if (beta is not None and db_acc is None) else None) + nret
@@ -587,7 +650,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.vfd_bn_act_backward_sums(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                                mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope,
                                                ctx.token["sums"].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc),
-                                               ptr(db_acc), stream()), "bn_act_backward_sums")
+                                               ptr(db_acc), ptr(cs_acc), stream()), "bn_act_backward_sums")
             return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
                     dbeta if (beta is not None and db_acc is None) else None) + nret
         check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
@@ -598,7 +661,7 @@ class _BnAct(torch.autograd.Function):
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,
-           sums=None, num_batches_tracked=None, bwd_sums=None):
+           sums=None, num_batches_tracked=None, bwd_sums=None, conv_bias=None, bias_token=None):
     """Training-mode batch normalisation over all rows of `x` followed by `act`; updates the running statistics
     in place (momentum rule, unbiased variance) exactly like torch.nn.BatchNormNd.train(); `num_batches_tracked`
     (int64 device scalar) is incremented by the statistics kernel."""
@@ -606,7 +669,7 @@ def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, ac
         raise TypeError("num_batches_tracked must be an int64 device tensor")
     token = {"sums": bwd_sums} if bwd_sums is not None else None
     y = _BnAct.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act),
-                     float(slope), sums, num_batches_tracked, token)
+                     float(slope), sums, num_batches_tracked, token, conv_bias, bias_token)
     out = ClTensor(y, x.C, x.nsp)
     out.fused_bn = token      # `bwd_sums`: zeroed [STATS_REPLICAS][2][CPAD(C)] buffer; y must have exactly ONE consumer conv
     return out

@@ -57,12 +57,11 @@ class GraphedStep:
             program = m.step_program()
         else:
             program = [("graph", self._eager_step)]
-        # Packed filter copies are cached per parameter (functional._packed_filter).  A copy made BEFORE the capture and
-        # still valid at a net's first use inside it (AnoGAN: netD is re-packed at the end of step k, after its Adam update,
-        # and first used again at the start of step k+1) would be read by the captured kernels at its pre-capture address
-        # for ever — stale weights, and a dangling pointer once the cache replaces the tensor.  Invalidating every copy
-        # here makes each net's first use inside the capture produce its packs inside the graph.
-        F.invalidate_weight_cache()
+        # Packed filter copies (functional._packed_filter) live in buffers that are allocated once and re-packed in place,
+        # and every optimiser re-packs all copies of its filters in one launch right after its update (optim.Adam.step ->
+        # functional.repack_owned), which is captured with the step: a replay therefore always reads current weights at
+        # stable addresses.  (Round-2 history: copies used to be re-allocated on a miss, and a copy that was still valid
+        # at a net's first use inside the capture was read at its pre-capture address for ever.)
         reducers = {id(r): r for kind, r in program if kind != "graph"}.values()
         for r in reducers:
             r.suspended = True         # no collective may be issued while a capture is open

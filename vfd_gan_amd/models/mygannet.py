@@ -30,8 +30,10 @@ def _conv_bn_act(block, x, slope):
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
         buf = torch.zeros(2 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums: one fill
-        x = block.conv(x, stats=buf[:k])
-        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:])
+        tbias = block.conv.temporal_conv.bias
+        tok = {"taken": False} if tbias is not None else None
+        x = block.conv(x, stats=buf[:k], bias_token=tok)
+        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:], conv_bias=tbias, bias_token=tok)
     x = block.conv(x)
     return block.bn(x, act=_lib.ACT_LRELU, slope=slope)
 

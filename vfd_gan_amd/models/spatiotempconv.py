@@ -36,13 +36,14 @@ class SpatioTemporalConv(tnn.Module):
         self.temporal_conv = hnn.Conv3d(intermed_channels, out_channels, temporal_kernel_size,
                                         stride=temporal_stride, padding=temporal_padding, bias=bias)
 
-    def forward(self, x, stats=None):
+    def forward(self, x, stats=None, bias_token=None):
         """spatial conv -> BatchNorm+ReLU (one fused pass; bf16: statistics from the conv epilogue) -> temporal conv (bf16: its
         data gradient carries the BatchNorm+ReLU backward reduce, nn.run_fused).
         `stats` (optional [2*Cp] float32 zeros) receives the temporal conv's per-channel sum / sum of squares for the
-        BatchNorm the callers apply next (models/mygannet.py:24-26,113-115)."""
+        BatchNorm the callers apply next (models/mygannet.py:24-26,113-115); `bias_token`: that BatchNorm's backward also
+        produces the temporal conv's bias gradient (functional.bn_act)."""
         plain = not isinstance(x, ClTensor)
         if plain:
             x = F.to_cl(x)
-        x = hnn.run_fused([self.spatial_conv, self.bn, self.relu, self.temporal_conv], x, last_stats=stats)
+        x = hnn.run_fused([self.spatial_conv, self.bn, self.relu, self.temporal_conv], x, last_stats=stats, last_bias_token=bias_token)
         return x.to_torch() if plain else x

@@ -41,7 +41,7 @@ def _act_of(m):
 class _ConvMixin:
     _transposed = False
 
-    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None, claim_act_grad=False):
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None, claim_act_grad=False, bias_token=None):
         _need_cl(x, type(self).__name__)
         if self.groups != 1 or any(d != 1 for d in self.dilation):
             raise NotImplementedError("groups/dilation are not used by the reference nets")
@@ -49,7 +49,7 @@ class _ConvMixin:
             raise NotImplementedError("padding_mode %r" % (self.padding_mode,))
         op = self.output_padding if self._transposed else 0
         return F.conv(x, self.weight, self.bias, self.stride, self.padding, op, self._transposed, act, slope, stats,
-                      claim_act_grad)
+                      claim_act_grad, bias_token)
 
 
 class Conv3d(_ConvMixin, tnn.Conv3d):
@@ -90,7 +90,7 @@ class Linear(tnn.Linear):
 
 # ---- normalisation ---------------------------------------------------------------------------------------------
 class _BatchNormMixin:
-    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, sums=None, bwd_sums=None):
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, sums=None, bwd_sums=None, conv_bias=None, bias_token=None):
         _need_cl(x, type(self).__name__)
         if x.C != self.num_features:
             raise RuntimeError("BatchNorm: %d channels, expected %d" % (x.C, self.num_features))
@@ -103,7 +103,8 @@ class _BatchNormMixin:
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         nbt = self.num_batches_tracked if self.track_running_stats else None      # += 1 inside the statistics kernel
-        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums)
+        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums,
+                        conv_bias, bias_token)
 
 
 class BatchNorm3d(_BatchNormMixin, tnn.BatchNorm3d):
@@ -176,11 +177,12 @@ _BNS = (BatchNorm3d, BatchNorm2d, BatchNorm1d)
 _NO_HANDOVER = bool(os.environ.get("VFD_NO_ACT_HANDOVER"))    # tuning / bisecting switch
 
 
-def run_fused(mods, x, last_stats=None):
+def run_fused(mods, x, last_stats=None, last_bias_token=None):
     """Run a list of HIP-backed layers, fusing conv->act into the conv epilogue, BatchNorm->act into one
     normalise+activate pass, (bf16) conv->BatchNorm statistics into the conv epilogue, and the activation / BatchNorm
-    backward of a producer into the data-gradient epilogue of the conv that consumes it.  `last_stats`: statistics buffer
-    for the list's LAST layer (a conv whose BatchNorm the caller applies itself)."""
+    backward of a producer into the data-gradient epilogue of the conv that consumes it.  `last_stats` / `last_bias_token`:
+    statistics buffer / bias-gradient token (see F.bn_act) for the list's LAST layer, a conv whose BatchNorm the caller
+    applies itself."""
     i, n = 0, len(mods)
     fresh = False      # x is the (single-consumer) output of a conv+activation or BatchNorm(+activation) of this list
     epi = use_epilogue_stats(x)
@@ -213,14 +215,17 @@ def run_fused(mods, x, last_stats=None):
         pool_off += k
         return buf
 
-    def run_bn(j, x, sums):
-        """BatchNorm at j with the activation that follows it; returns (x, next index, x has a hand-over token)."""
+    def run_bn(j, x, sums, conv=None, tok=None):
+        """BatchNorm at j with the activation that follows it; returns (x, next index, x has a hand-over token).  `conv`
+        (with bias token `tok`): the conv that feeds it — its bias gradient is the column sum of this BatchNorm's dx."""
         bn = mods[j]
         nxt_i = bn_span(j)
         a = _act_of(mods[j + 1]) if nxt_i == j + 2 else None
         kw = {"act": a[0], "slope": a[1]} if a is not None else {}
         if bn.training and pool is not None:
             kw["bwd_sums"] = take(bn.num_features)      # backward: reduce with atomics + folding apply, or the conv hand-over
+            if tok is not None:
+                kw["conv_bias"], kw["bias_token"] = conv.bias, tok
         give = handover and "bwd_sums" in kw and is_conv(nxt_i)
         return bn(x, sums=sums, **kw) if sums is not None else bn(x, **kw), nxt_i, give
 
@@ -240,11 +245,16 @@ def run_fused(mods, x, last_stats=None):
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and epi:
                 sums = take(m.out_channels)
+                tok = {"taken": False} if m.bias is not None else None
+                if tok is not None:
+                    kw["bias_token"] = tok
                 x = m(x, stats=sums, **kw)
-                x, i, fresh = run_bn(i + 1, x, sums)
+                x, i, fresh = run_bn(i + 1, x, sums, m, tok)
                 continue
             if last_stats is not None and i == n - 1:
                 kw["stats"] = last_stats
+                if last_bias_token is not None:
+                    kw["bias_token"] = last_bias_token
             x = m(x, **kw)
             i += 1
             continue

@@ -76,6 +76,7 @@ class Adam(torch.optim.Optimizer):
                                        float(g["eps"]), self._step_dev.data_ptr(), self._bc_dev.data_ptr(),
                                        float(self.grad_scale), stream()), "adam_step_dev")
         self._epoch[0] += 1          # the kernel wrote through raw pointers: no torch version bump
+        F.repack_owned(self._epoch)  # ... and every packed (bf16, K-major) copy of these filters follows in one launch
 
     # ---- resume support (the reference saves no optimiser state) -------------------------------
     def state_dict(self):
