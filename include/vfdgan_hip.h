@@ -157,6 +157,10 @@ int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes);
 int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
                    void* stream);
 int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream);
+/* ... and, in the same launch, db[Cout] += the fold of bias_rep[VFD_STATS_REPLICAS][CPAD(Cout)] (see
+ * vfd_bn_backward_apply_sums: the layer's bias gradient when a BatchNorm consumes its output).                   */
+int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
+                          float* db, void* stream);
 /* Dispatch switch of the halo-tiled filter-gradient kernel (conv_wgrad_halo.hip: stride-1 layers with a 3 x 3 in-plane
  * footprint, kd 1 or 3, >= 33 channels on both sides, bf16): 0 = default rules, 1 = never (conv_wgrad's per-tap
  * gather), 2 = whenever eligible (tests).  Returns the previous mode.  vfd_wgrad_workspace / vfd_conv_wgrad /
@@ -205,9 +209,10 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
 /* The apply pass alone, for a gradient that arrives as g = dy*act'(.) with sums[VFD_STATS_REPLICAS][2][Cp] = the
  * per-channel sums of g and g*xhat (vfd_conv_forward_bn_backward): dgamma/dbeta are published by the first row of
  * workgroups (OVERWRITTEN; *_acc ACCUMULATED into), dx as above.  One launch instead of three.
- * colsum_acc (NULL or float32[C], ACCUMULATED into with float atomics): the per-channel sums of dx, i.e. the bias
- * gradient of the convolution that feeds this BatchNorm (nn.Conv3d(bias=True) -> BatchNorm3d, models/anogan.py:44-70)
- * without vfd_bias_grad's own pass over dx.                                                                       */
+ * colsum_acc (NULL or float32 [VFD_STATS_REPLICAS][Cp], pre-zeroed, ACCUMULATED into with float atomics): the
+ * per-channel sums of dx in replica rows, i.e. the bias gradient of the convolution that feeds this BatchNorm
+ * (nn.Conv3d(bias=True) -> BatchNorm3d, models/anogan.py:44-70) without vfd_bias_grad's own pass over dx;
+ * vfd_wgrad_reduce_bias folds the rows into the parameter's gradient.                                              */
 int vfd_bn_backward_apply_sums(int dtype, const void* x, const void* g, void* dx, int64_t rows, int C,
                                const float* mean, const float* rstd, const float* gamma, const float* sums,
                                float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, float* colsum_acc,

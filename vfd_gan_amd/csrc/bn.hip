@@ -197,18 +197,40 @@ template <int ACT> __device__ __forceinline__ float act_grad_in_c(float x, float
   else return 1.f;
 }
 
-// Sums of 8 consecutive channels over the replica rows a conv epilogue wrote ([VFD_STATS_REPLICAS][2][Cp], common.hpp),
-// folded in double in replica order: every thread that owns the granule gets the same bits.
-__device__ __forceinline__ void fold_replicas8(const float* __restrict__ sums, int Cp, int g, double (&s1)[8], double (&s2)[8]) {
+// Sums of 8 consecutive channels (granule g) over the replica rows a conv epilogue wrote ([VFD_STATS_REPLICAS][2][Cp],
+// common.hpp).  The TY row-lanes of a granule share the rows (lane ty loads rows ty, ty + TY, ...: 4 16-byte loads each —
+// one thread loading all 8 rows either keeps 128 registers of loads in flight or pays 8 dependent L2 round trips), LDS
+// brings them together and every lane adds the 8 partials in row order, in double: the same bits in every workgroup.
+// EVERY thread of the workgroup must call it (one barrier).
+__device__ __forceinline__ void fold_replicas8(const float* __restrict__ sums, int Cp, int g, bool live, int tx, int ty, int TX, int TY,
+                                               float (*sh)[16 + 1], double (&s1)[8], double (&s2)[8]) {
+  static_assert(VFD_STATS_REPLICAS == 8, "row-lane split below");
+  float pa[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) pa[k] = 0.f;
+  if (live) {
+    for (int r = ty; r < VFD_STATS_REPLICAS; r += TY) {
+      const float4* a = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + g * 8);
+      const float4* b = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + Cp + g * 8);
+      const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+      if (TY >= VFD_STATS_REPLICAS) {      // one row per lane: the partial IS the row
+        pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+        pa[8] = b0.x; pa[9] = b0.y; pa[10] = b0.z; pa[11] = b0.w; pa[12] = b1.x; pa[13] = b1.y; pa[14] = b1.z; pa[15] = b1.w;
+      } else {
+        pa[0] += a0.x; pa[1] += a0.y; pa[2] += a0.z; pa[3] += a0.w; pa[4] += a1.x; pa[5] += a1.y; pa[6] += a1.z; pa[7] += a1.w;
+        pa[8] += b0.x; pa[9] += b0.y; pa[10] += b0.z; pa[11] += b0.w; pa[12] += b1.x; pa[13] += b1.y; pa[14] += b1.z; pa[15] += b1.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sh[threadIdx.x][k] = pa[k];
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 8; ++k) { s1[k] = 0; s2[k] = 0; }
+  const int nl = TY < VFD_STATS_REPLICAS ? TY : VFD_STATS_REPLICAS;
+  for (int j = 0; j < nl; ++j) {
 #pragma unroll
-  for (int r = 0; r < VFD_STATS_REPLICAS; ++r) {
-    const float4* a = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + g * 8);
-    const float4* b = reinterpret_cast<const float4*>(sums + (size_t)r * 2 * Cp + Cp + g * 8);
-    const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-    s1[0] += a0.x; s1[1] += a0.y; s1[2] += a0.z; s1[3] += a0.w; s1[4] += a1.x; s1[5] += a1.y; s1[6] += a1.z; s1[7] += a1.w;
-    s2[0] += b0.x; s2[1] += b0.y; s2[2] += b0.z; s2[3] += b0.w; s2[4] += b1.x; s2[5] += b1.y; s2[6] += b1.z; s2[7] += b1.w;
+    for (int k = 0; k < 8; ++k) { s1[k] += (double)sh[j * TX + tx][k]; s2[k] += (double)sh[j * TX + tx][8 + k]; }
   }
 }
 
@@ -233,14 +255,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
+  __shared__ float sh_fold[SUMS ? 256 : 1][16 + 1];
+  double s1[8], s2[8];
   if constexpr (SUMS) {
     if (sa.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sa.nbt += 1;      // BatchNorm.num_batches_tracked
+    fold_replicas8(sa.sums, Cp, g, g < GR, tx, ty, TX, TY, sh_fold, s1, s2);
   }
   if (g >= GR) return;
   float sc[8], sf[8];
   if constexpr (SUMS) {
-    double s1[8], s2[8];
-    fold_replicas8(sa.sums, Cp, g, s1, s2);
     const double n = (double)rows, inv_n = 1.0 / n;
     const bool publish = blockIdx.y == 0 && ty == 0;
 #pragma unroll
@@ -455,29 +478,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
-  __shared__ float sh_cs[256][8 + 1];
+  __shared__ float sh_cs[256][16 + 1];     // replica fold, then the column-sum fold
+  double s1[8], s2[8];
+  fold_replicas8(sums, Cp, g, g < GR, tx, ty, TX, TY, sh_cs, s1, s2);
   if (g >= GR) {
-    if (colsum_acc != nullptr) __syncthreads();      // matches the barrier of the column-sum fold at the end
+    if (colsum_acc != nullptr) { __syncthreads(); __syncthreads(); }      // the two barriers of the column-sum fold at the end
     return;
   }
-  float mu[8], rs[8], gr[8], c1[8], c2[8], ga[8], be[8], cs[8];
+  // dx = gamma*rstd*(g - mean(g) - xh*mean(g*xh)) with xh = (x - mu)*rstd, re-associated into dx = g*A + x*B + D, and
+  // z = gamma*xh + beta = x*E + F for the activation derivative: 5 constants per channel instead of 7 (this kernel
+  // streams 4 rows x 2 tensors per thread; at 7 it needed 188 registers, i.e. 2 waves per SIMD)
+  float A[8], B[8], D[8], E[8], Fz[8], cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
   const float inv = 1.f / (float)rows;
   {
-    double s1[8], s2[8];
-    fold_replicas8(sums, Cp, g, s1, s2);
     const bool publish = blockIdx.y == 0 && ty == 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int c = g * 8 + k;
       const bool ok = c < C;
       const float sg = (float)s1[k], sgx = (float)s2[k];
-      mu[k] = ok ? mean[c] : 0.f; rs[k] = ok ? rstd[c] : 0.f;
-      ga[k] = ok ? (gamma ? gamma[c] : 1.f) : 0.f;
-      be[k] = (ok && beta) ? beta[c] : 0.f;
-      gr[k] = ga[k] * rs[k];
-      c1[k] = ok ? sg * inv : 0.f; c2[k] = ok ? sgx * inv : 0.f;
+      const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
+      const float ga = ok ? (gamma ? gamma[c] : 1.f) : 0.f, be = (ok && beta) ? beta[c] : 0.f;
+      const float gr = ga * rs, c1 = ok ? sg * inv : 0.f, c2 = ok ? sgx * inv : 0.f;
+      A[k] = gr;
+      B[k] = -rs * gr * c2;
+      D[k] = -gr * c1 + mu * rs * gr * c2;
+      E[k] = rs * ga;
+      Fz[k] = be - mu * rs * ga;
       if (ok && publish) {
         dbeta[c] = sg;
         dgamma[c] = sgx;
@@ -503,10 +532,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
       const long long ru = r + (long long)u * TY;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float xh = (v[u][k] - mu[k]) * rs[k];
         float gzv = d[u][k];
-        if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
-        d[u][k] = gr[k] * (gzv - c1[k] - xh * c2[k]);
+        if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[u][k] * E[k] + Fz[k], slope);
+        d[u][k] = gzv * A[k] + (v[u][k] * B[k] + D[k]);
       }
       if (ru < rend) {
         store8(dx + ru * Cp + g * 8, d[u]);
@@ -516,9 +544,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
     }
   }
   // bias gradient of the convolution that feeds this BatchNorm: the column sums of dx, folded over the row-lanes and
-  // added to the parameter's gradient (one float atomic per channel and workgroup) — the separate column-sum pass over dx
-  // (vfd_bias_grad: one more read of the tensor and two launches) is gone
+  // added into a replica row of colsum_acc[VFD_STATS_REPLICAS][Cp] (one float atomic per channel and workgroup; straight
+  // into the gradient, 512 workgroups per address, the atomics alone took 80 us) — the separate column-sum pass over dx
+  // (vfd_bias_grad: one more read of the tensor and two launches) is gone; vfd_wgrad_reduce_bias folds the replicas
   if (colsum_acc != nullptr) {
+    __syncthreads();      // every lane is done reading the replica fold from sh_cs
 #pragma unroll
     for (int k = 0; k < 8; ++k) sh_cs[threadIdx.x][k] = cs[k];
     __syncthreads();
@@ -528,7 +558,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
         for (int k = 0; k < 8; ++k) cs[k] += sh_cs[j * TX + tx][k];
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        if (g * 8 + k < C) atomicAdd(colsum_acc + g * 8 + k, cs[k]);
+        if (g * 8 + k < C) atomicAdd(colsum_acc + (size_t)(blockIdx.y % VFD_STATS_REPLICAS) * Cp + g * 8 + k, cs[k]);
     }
   }
 }

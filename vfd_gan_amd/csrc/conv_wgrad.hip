@@ -262,8 +262,22 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
 // 1 KiB per wave-load; Cbp is a multiple of 8, so the four share a tap); 64 quads x 4 split-lanes per workgroup: every
 // split-lane folds a quarter of the slabs with 4 loads in flight, LDS sums the lanes in a fixed order (bitwise
 // reproducible), and the sums go to the torch layout.
+// Workgroups past `wblocks` (bias_rep != null) fold the layer's BIAS gradient instead: the column sums of the output
+// gradient that the consuming BatchNorm's apply pass left in replica rows bias_rep[VFD_STATS_REPLICAS][Cbp] are added to
+// the parameter's gradient db[Cb] (vfd_bn_backward_apply_sums; a separate fold launch would cost as much as it does).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B,
-                                                           int T, int Bp, int nsplit, float beta) {
+                                                           int T, int Bp, int nsplit, float beta, long long wblocks,
+                                                           const float* __restrict__ bias_rep, float* __restrict__ db, int Cb, int Cbp) {
+  if ((long long)blockIdx.x >= wblocks) {
+    const int c = (int)(blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (c < Cb) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += bias_rep[(size_t)r * Cbp + c];
+      db[c] += v;
+    }
+    return;
+  }
   const int ncols = T * Bp;
   const int qpr = ncols >> 2;                      // column quads per filter row
   const long long nquads = (long long)A * qpr;
@@ -437,15 +451,28 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   return VFD_OK;
 }
 
-extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream) {
+static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep, float* db,
+                               void* stream) {
   WgGeom g;
   int rc = make_geom(d, g);
   if (rc != VFD_OK) return rc;
   VFD_REQUIRE(ws && dw, "wgrad_reduce: null pointer");
   const long long nquads = (long long)g.A * ((g.T * g.p.Cgp) >> 2);
   const long long blocks = (nquads + 63) / 64;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                     reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta);
+  const int extra = bias_rep != nullptr ? (d->Cout + 255) / 256 : 0;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta, blocks, bias_rep, db, d->Cout,
+                     cpad(d->Cout));
   VFD_CHECK_LAUNCH("wgrad_reduce");
   return VFD_OK;
+}
+
+extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream) {
+  return wgrad_reduce_launch(d, ws, dw, beta, nullptr, nullptr, stream);
+}
+
+extern "C" int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
+                                     float* db, void* stream) {
+  VFD_REQUIRE(d && bias_rep && db, "wgrad_reduce_bias: null pointer");
+  return wgrad_reduce_launch(d, ws, dw, beta, bias_rep, db, stream);
 }

@@ -498,6 +498,7 @@ class _Conv(torch.autograd.Function):
             gy = g
         A, B = (Cin, Cout) if transposed else (Cout, Cin)
         gx = gw = gb = None
+        bias_done = False
         if ctx.needs_input_grad[0]:
             # data gradient = the opposite kind of convolution with the A/B-swapped filter packing
             packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
@@ -522,13 +523,20 @@ class _Conv(torch.autograd.Function):
                 check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64), "wgrad_kernel_name")
                 timer.records.append((buf.value.decode(), _conv_flops(desc), e0, e1, _geom_str(desc)))
             direct = _direct_grad(weight)
-            if direct is not None:
+            tok = ctx.bias_token
+            bdirect = _direct_grad(ctx.bias_param) if (tok is not None and tok["taken"] and ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if direct is not None and bdirect is not None:
+                # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias gradient)
+                # in replica rows: folded by the same launch
+                check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
+                                                bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
+                bias_done = True
+            elif direct is not None:
                 check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
-        if ctx.has_bias and ctx.needs_input_grad[2] and not (ctx.bias_token is not None and ctx.bias_token["taken"]):
-            # (taken: the BatchNorm that consumes this conv's output has already added the column sums of its dx)
+        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
             bias = ctx.bias_param
             direct = _direct_grad(bias)
             bws = _workspace(lib.vfd_bias_grad_workspace(Cout), x.device)
@@ -612,7 +620,7 @@ class _BnAct(torch.autograd.Function):
             # x is conv(..) + conv_bias: the bias gradient is the column sum of THIS backward's dx, which the apply pass has
             # in registers; the conv then skips its own column-sum pass over dx
             bias_token["taken"] = True
-            ctx.conv_bias = conv_bias
+            ctx.conv_bias = bias_token["rep"]      # zeroed [STATS_REPLICAS][CPAD(C)] rows; folded by the conv's vfd_wgrad_reduce_bias
         if token is not None:
             # what the consumer conv's data-gradient epilogue needs to take over the reduce pass of this backward
             token.update(x=x, mean=mean, rstd=rstd, gamma=g_, beta=b_, act=act, slope=slope, claimed=False)
@@ -634,7 +642,7 @@ class _BnAct(torch.autograd.Function):
         dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
         db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
         nret = (None,) * 12
-        cs_acc = _direct_grad(ctx.conv_bias) if ctx.conv_bias is not None else None
+        cs_acc = ctx.conv_bias
         if ctx.token is not None and ctx.token["claimed"]:
             # gy is already g = dy * act'(z) and the sums of g, g*xhat sit in the token's buffer (written by the consumer's
             # data gradient): only the apply pass is left

@@ -29,11 +29,11 @@ def _conv_bn_act(block, x, slope):
     conv's epilogue (bf16) and normalise+activate in one pass."""
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
-        buf = torch.zeros(2 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums: one fill
+        buf = torch.zeros(3 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums | bias sums: one fill
         tbias = block.conv.temporal_conv.bias
-        tok = {"taken": False} if tbias is not None else None
+        tok = {"taken": False, "rep": buf[2 * k:]} if tbias is not None else None
         x = block.conv(x, stats=buf[:k], bias_token=tok)
-        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:], conv_bias=tbias, bias_token=tok)
+        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:2 * k], conv_bias=tbias, bias_token=tok)
     x = block.conv(x)
     return block.bn(x, act=_lib.ACT_LRELU, slope=slope)
 

@@ -203,7 +203,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
         for j, m in enumerate(mods):
             if isinstance(m, _BNS) and m.training:
                 if j > 0 and is_conv(j - 1):
-                    need += F.stats_buffer_numel(m.num_features)
+                    need += F.stats_buffer_numel(m.num_features) * (2 if mods[j - 1].bias is not None else 1)
                 need += F.stats_buffer_numel(m.num_features)      # backward sums (every training BatchNorm)
         if need:
             pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
@@ -245,7 +245,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and epi:
                 sums = take(m.out_channels)
-                tok = {"taken": False} if m.bias is not None else None
+                tok = {"taken": False, "rep": take(m.out_channels)} if m.bias is not None else None
                 if tok is not None:
                     kw["bias_token"] = tok
                 x = m(x, stats=sums, **kw)
