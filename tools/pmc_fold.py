@@ -31,10 +31,11 @@ def short(name):
         tile = {("2", "2"): "128c_x_128p", ("2", "4"): "128c_x_256p", ("4", "2"): "256c_x_128p", ("4", "4"): "256c_x_256p"}.get((a[1], a[2]))
         if tile is None:
             tile = "%dc_x_256p" % (16 * int(a[3]))
-        return "conv_igemm<%s,%s>" % (dt, tile)
-    m = re.search(r"conv_halo_kernel<(\d+), (\d+), (\d+)", name)
+        bn = "+bn_bwd" if len(a) > 7 and a[7] == "true" else ""      # the BatchNorm hand-over epilogue variant
+        return "conv_igemm<%s,%s>%s" % (dt, tile, bn)
+    m = re.search(r"conv_halo_kernel<(\d+), (\d+), (\d+), (\d+)", name)
     if m:
-        return "conv_halo<bf16,%sc_x_256p>" % m.group(1)
+        return "conv_halo<bf16,%sc_x_256p>%s" % (m.group(1), "+bn_bwd" if int(m.group(4)) & 64 else "")
     if "conv_wgrad_halo_kernel" in name:
         return "conv_wgrad_halo<bf16>"
     if "conv_cin8_kernel" in name:

@@ -433,7 +433,9 @@ def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None, bn=None):
               "conv_forward")
     if timer is not None:
         e1.record()
-        timer.records.append((_conv_kernel_name(desc, stats), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
+        # (the BatchNorm hand-over runs an epilogue variant of its own, which also does BatchNorm's backward reduce: its own row)
+        timer.records.append((_conv_kernel_name(desc, stats) + ("+bn_bwd" if bn is not None else ""), _conv_flops(desc), e0, e1,
+                              _geom_str(desc, stats)))
 
 
 class _Conv(torch.autograd.Function):
