@@ -158,7 +158,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU")
     ap.add_argument("--isize", type=int, default=None)
     ap.add_argument("--nfr", type=int, default=16)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: bf16 storage, e4m3 operands for the forward / data-gradient GEMMs of the wide layers (functional.set_fp8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying a hipGraph")
@@ -179,7 +180,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dev = torch.device("cuda", torch.cuda.current_device())
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8"}[a.dtype]
 
     model = build_model(a.model, make_args(a.model, a.batch, a.nfr, a.isize, local), dtype)
     batch = synthetic_batch(a.batch, a.nfr, a.isize, 3, seed=1234 + rank)
@@ -272,7 +273,7 @@ def main():
 
     if rank == 0:
         clips_s = world * a.batch * a.steps / elapsed
-        peak = MFMA_PEAK_BF16_TFLOPS if a.dtype == "bf16" else MFMA_PEAK_F32_TFLOPS
+        peak = MFMA_PEAK_F32_TFLOPS if a.dtype == "f32" else MFMA_PEAK_BF16_TFLOPS      # (fp8 mode: priced against bf16, most FLOPs stay bf16)
         names = {"ganomaly": "ganomaly 16x%d x%d %s batch=%d clips/GPU (BASELINE.json configs[1]): frames folded to (%d,3,%d,%d), "
                              "generalised pyramid 112-56-28-14-7, nz=100 ngf=64, full optimize_params (G fwd, 4 D fwd, backward_g, "
                              "Adam, backward_d, Adam)" % (a.isize, a.isize, a.dtype, a.batch, a.batch * a.nfr, a.isize, a.isize),

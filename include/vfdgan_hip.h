@@ -30,6 +30,7 @@ extern "C" {
 
 #define VFD_F32 0
 #define VFD_BF16 1
+#define VFD_FP8 2     /* OCP e4m3fn bytes, 16 channels per granule (CPAD16); convolution OPERANDS only (vfd_conv_forward_fp8) */
 
 #define VFD_OK 0
 #define VFD_EINVAL (-1)   /* bad argument (shape/dtype/alignment) */
@@ -112,6 +113,24 @@ int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, 
  * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
 int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes);
 
+/* ---- fp8 operands (BASELINE configs[4]: "fp8 weights/activations (CDNA4 fp8 MFMA)") --------------------------------
+ * OCP e4m3fn, per-tensor CURRENT scaling: vfd_amax takes max|x| of the tensor into a device scalar (zeroing it first),
+ * vfd_quantize_fp8 writes x_q = e4m3(x * 448 / amax) with 16 channels per granule ([rows][CPAD16(C)]; amax == NULL:
+ * scale 1) and publishes the scale it used in *scale_out; vfd_pack_filter_fp8 does both for a filter (same index map as
+ * vfd_pack_filter, channels padded to 16).  vfd_conv_forward_fp8 (d->dtype == VFD_FP8) = the implicit GEMM on
+ * v_mfma_f32_16x16x128_f8f6f4 (twice the bf16 FLOPs per clock): y (bf16) = act(acc / (*scale_x * *scale_w) + bias), optional
+ * BatchNorm statistics as vfd_conv_forward.  The scales are read on the device, so a captured step follows them.
+ * Serves the forward pass and, with the A/B-swapped packing, the data gradient (as for bf16).                      */
+int vfd_amax(int dtype, const void* x, int64_t rows, int C, float* amax, void* stream);
+int vfd_quantize_fp8(int dtype, const void* x, void* q, int64_t rows, int C, const float* amax, float* scale_out,
+                     void* stream);
+int vfd_pack_filter_fp8(const float* w, void* packed, int A, int B, int T, int transpose_ab, float* amax,
+                        float* scale_out, void* stream);
+int vfd_dequantize_fp8(const void* q, float* y, int64_t n, const float* scale, void* stream);
+int vfd_conv_forward_fp8(const vfd_conv_desc* d, const void* x, const float* scale_x, const void* packed,
+                         const float* scale_w, const float* bias, void* y, float* stats, size_t stats_bytes,
+                         void* stream);
+
 /* y = (conv(x, packed) + bias) * act'(mul_src), mul_src a tensor of y's shape and dtype holding the OUTPUT of an
  * activation (LeakyReLU / Sigmoid / Tanh, derivative taken from the output).  This is the data gradient of a layer
  * whose input was produced by a conv with a fused activation (nn.Sequential(Conv, LeakyReLU, Conv, ...),
@@ -188,6 +207,11 @@ int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float
 int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean,
                            float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                            void* stream);
+/* One more running-statistics update (and counter increment) from batch statistics already at hand: stands in for a
+ * forward that the reference repeats on identical input and weights (models/ganomaly.py:485 evaluates netd(input) a
+ * second time inside backward_g; only its BatchNorm side effect differs from re-using the first result).            */
+int vfd_bn_running_update(const float* mean, const float* rstd, int64_t rows, int C, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
 /* y = act((x-mean)*rstd*gamma + beta) */
 int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* mean,
                        const float* rstd, const float* gamma, const float* beta, int act, float slope,

@@ -179,6 +179,46 @@ def test_ganomaly_bench_config_bf16_ngf64_112(dev, tmp_path):
     assert not bad, bad
 
 
+def test_ganomaly_step_fp8_operands_112(dev, tmp_path):
+    """BASELINE configs[4]'s arithmetic on configs[1]'s geometry: ngf=64, isize 112, one full optimize_params with e4m3
+    operands for the forward / data-gradient GEMMs of the wide layers (functional.set_fp8; conv_igemm<fp8,..>), against the
+    float32 oracle.  The reference has no fp8 fixture ("unpinned, report vs the bf16 run"), so the gate is
+    the bf16 gate widened for e4m3's 3 mantissa bits: the reconstruction / encoder losses within 1e-1, the adversarial BCE
+    terms (a sigmoid of the classifier's sum over e4m3-rounded features) within 2.5e-1, generated frames within 2e-1
+    relative RMS (measured 0.14: ~8 stacked e4m3 layers at 2^-4 relative rounding each) — and both fp8 tiles must actually
+    have run."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.lib.data import synthetic_batch
+    from vfd_oracle import ganomaly as OG
+    B, T, S, ngf = 1, 16, 112, 64
+    model, og, od, opt = _build(tmp_path, dev, torch.bfloat16, B, T, S, ngf)
+    opt_g, opt_d = OG.make_optimizers(og, od, opt)
+    batch = synthetic_batch(B, T, S, 3, seed=321)
+    errs_ref, fake_ref = OG.step(og, od, opt_g, opt_d, OG.fold_frames(batch[0]), opt)
+    prev = F.set_fp8(True)
+    prev_min, F._FP8_MIN_OUT[0] = F._FP8_MIN_OUT[0], 65          # both fp8 tiles
+    timer = F.KernelTimer()
+    F.set_kernel_timer(timer)
+    try:
+        model.set_input(batch)
+        model.optimize_params(check_collapse=False)
+        torch.cuda.synchronize()
+    finally:
+        F.set_kernel_timer(None)
+        F.set_fp8(prev)
+        F._FP8_MIN_OUT[0] = prev_min
+    names = {r[0] for r in timer.records}
+    assert "conv_igemm<fp8,256c_x_256p>" in names and "conv_igemm<fp8,128c_x_128p>" in names, names
+    errs = model.errors()
+    for k, v in errs_ref.items():
+        got = errs["%s/%s/train" % (k[4], k)]
+        tol = 2.5e-1 if k in ("err_d_real", "err_d_fake", "err_d", "err_g_adv") else 1e-1
+        assert abs(got - v) <= tol * max(abs(v), 1e-3), (k, got, v)
+    assert relrms(model.fake.to_torch(), fake_ref) < 2e-1, relrms(model.fake.to_torch(), fake_ref)
+    for n, prm in list(model.netg.named_parameters()) + list(model.netd.named_parameters()):
+        assert torch.isfinite(prm).all(), n
+
+
 def _smooth(net, make):
     """Replace every ReLU / LeakyReLU of a net's Sequentials by LeakyReLU(1.0) (identity, same kernels, no kink)."""
     import torch.nn as tnn

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
     ap.add_argument("--set", default="ganomaly", choices=["ganomaly", "anogan"], help="ganomaly: 2-D pyramid, 512 frames; anogan: 3-D layers, 32 clips")
+    ap.add_argument("--fp8", action="store_true", help="also time the e4m3 forward / data gradient of every layer with >= 16 channels")
     ap.add_argument("--halo", type=int, default=0, help="vfd_conv_set_halo_mode: 0 default rules, 1 never (conv_igemm), 2 always")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -108,8 +109,21 @@ def main():
             lib.vfd_wgrad_reduce(ctypes.byref(d_f), ws.data_ptr(), gw.data_ptr(), 0.0, st)
         t_w = timeit(wg, a.iters)
         tot["fwd"] += t_f; tot["dgrad"] += t_d; tot["wgrad"] += t_w
-        print("%-34s %10.1f %8.1f | %10.1f %8.1f | %10.1f %8.1f   (split %d)" % (name, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6,
-                                                                   t_w, flops / t_w / 1e6, nsplit.value))
+        extra = ""
+        if a.fp8 and cin >= 16 and cout >= 16:
+            # the same layer with e4m3 operands (forward and data gradient; the quantisation passes timed on their own)
+            xq, xs = F.quantize_fp8(x, cin)
+            gq, gs = F.quantize_fp8(gy, cout)
+            wq_f, ws_f = F.pack_filter_fp8(w, bool(tr), A, B, T)
+            wq_d, ws_d = F.pack_filter_fp8(w, not tr, A, B, T)
+            t8f = timeit(lambda: F.conv_fp8(xq, xs, wq_f, ws_f, None, N, dims, cin, odims, cout, kk, ss, pp, tr), a.iters)
+            t8d = timeit(lambda: F.conv_fp8(gq, gs, wq_d, ws_d, None, N, odims, cout, dims, cin, kk, ss, pp, not tr), a.iters)
+            t8q = timeit(lambda: F.quantize_fp8(x, cin), a.iters)
+            tot["fp8 fwd"] = tot.get("fp8 fwd", 0.0) + t8f
+            tot["fp8 dgrad"] = tot.get("fp8 dgrad", 0.0) + t8d
+            extra = "  || fp8 fwd %8.1f us %7.1f TF/s | dgrad %8.1f us %7.1f TF/s | quantise x %6.1f us" % (t8f, flops / t8f / 1e6, t8d, flops / t8d / 1e6, t8q)
+        print("%-34s %10.1f %8.1f | %10.1f %8.1f | %10.1f %8.1f   (split %d)%s" % (name, t_f, flops / t_f / 1e6, t_d, flops / t_d / 1e6,
+                                                                     t_w, flops / t_w / 1e6, nsplit.value, extra))
     print("totals us:", {k: round(v, 1) for k, v in tot.items()})
 
 

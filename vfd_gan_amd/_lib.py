@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvfdgan_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 LOSS_L2, LOSS_L1, LOSS_BCE, LOSS_WBCE = 0, 1, 2, 3
 
@@ -42,6 +42,11 @@ SIGNATURES = {
     "vfd_conv_set_bn_handover_min_channels": (c_int, [c_int]),
     "vfd_conv_forward_bn_backward": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
                                              c_vp, c_sz, c_vp]),
+    "vfd_amax": (c_int, [c_int, c_vp, c_i64, c_int, c_vp, c_vp]),
+    "vfd_quantize_fp8": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp]),
+    "vfd_pack_filter_fp8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "vfd_dequantize_fp8": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "vfd_conv_forward_fp8": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vfd_conv_forward_mul": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_conv_workspace": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_sz)]),
     "vfd_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
@@ -58,6 +63,7 @@ SIGNATURES = {
     "vfd_bn_workspace": (c_sz, [c_i64, c_int]),
     "vfd_bn_stats": (c_int, [c_int, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_stats_from_sums": (c_int, [c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vfd_bn_running_update": (c_int, [c_vp, c_vp, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "vfd_bn_act_forward_sums": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_int, c_f32, c_vp]),

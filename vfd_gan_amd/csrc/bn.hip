@@ -585,6 +585,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
     }                                                                                       \
   } while (0)
 
+// One more momentum update of the running statistics with batch statistics that are already known (mean, rstd of a
+// forward that would otherwise be repeated on identical input and weights): var = 1/rstd^2 - eps.
+__global__ void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, long long rows, int C,
+                                         float eps, float momentum, float* rmean, float* rvar, long long* nbt) {
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double rs = rstd[c];
+  double var = 1.0 / (rs * rs) - (double)eps;
+  if (var < 0) var = 0;
+  const double n = (double)rows;
+  if (rmean != nullptr) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+  if (rvar != nullptr) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(n > 1 ? var * n / (n - 1) : var);
+}
+
+extern "C" int vfd_bn_running_update(const float* mean, const float* rstd, int64_t rows, int C, float eps, float momentum,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
+  VFD_REQUIRE(mean && rstd && rows > 0 && C > 0, "bn_running_update: bad arguments");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), mean, rstd, (long long)rows, C, eps,
+                     momentum, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked));
+  VFD_CHECK_LAUNCH("bn_running_update");
+  return VFD_OK;
+}
+
 extern "C" size_t vfd_bn_workspace(int64_t rows, int C) {
   (void)rows;
   return (size_t)BN_MAX_BLOCKS * 3 * cpad(C) * sizeof(float);

@@ -8,6 +8,7 @@
 #include "../../include/vfdgan_hip.h"
 
 typedef uint16_t bf16_t;  // bfloat16 bit pattern
+struct fp8_t { uint8_t v; };   // OCP e4m3fn bit pattern (gfx950's native fp8: max 448, no infinities)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -65,6 +66,7 @@ int vfd_wgrad_halo_geom(const vfd_conv_desc* d, int* nsplit, size_t* bytes, WhGe
 int vfd_wgrad_halo_launch(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, hipStream_t st);
 
 static inline int cpad(int c) { return (c + 7) & ~7; }
+static inline int cpad16(int c) { return (c + 15) & ~15; }      // fp8 tensors: 16 channels per 16-byte granule
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- division by a launch-constant: q = floor(m / d) for 0 <= m < 2^31 --------------------------------------
@@ -152,6 +154,22 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
+// e4m3 through the hardware converters (v_cvt_pk_fp8_f32: round to nearest even, saturating at +-448; NaN stays NaN)
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+template <> struct Elem<fp8_t> {
+  static constexpr int VEC = 16;
+  __device__ static __forceinline__ float ld(const fp8_t* p) { return __builtin_amdgcn_cvt_f32_fp8((int)p->v, 0); }
+  __device__ static __forceinline__ void st(fp8_t* p, float v) { p->v = (uint8_t)(pack4_fp8(v, 0.f, 0.f, 0.f) & 0xffu); }
+};
+// a convolution's OUTPUT element type for an operand type: fp8 operands accumulate in f32 and leave as bf16 (the
+// BatchNorm / activation pass that follows re-quantises)
+template <typename T> struct OutOf { typedef T type; };
+template <> struct OutOf<fp8_t> { typedef bf16_t type; };
 
 // 8 consecutive channels (one CPAD granule) <-> 8 floats
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {

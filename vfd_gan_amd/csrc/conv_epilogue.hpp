@@ -19,16 +19,20 @@ struct EpiP {
   int act;
   float slope;
   MulP mul;              // mul.src non-null: gradient hand-over (common.hpp), mul.src has y's shape
+  float oscale;          // SCALED kernels (fp8 operands): the accumulator is multiplied by this first (1 / (scale_x * scale_w))
 };
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, bool BN, typename OutOff, typename RowValid>
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, bool BN, bool SCALED, typename OutOff, typename RowValid>
 __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], const EpiP& p, int n0, int stats_replica,
                                               OutOff out_offset, RowValid row_valid) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
   constexpr int NWAVES = WAVES_C * WAVES_P;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (fp8 tiles: the lane index is re-derived from the exec mask count instead of threadIdx.x, which would otherwise be the
+  // one value that has to survive the main loop in a VGPR — spilled at the 128-register cap of the 16-wave tile)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = SCALED ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)(threadIdx.x & 63);
+  const int tid = SCALED ? wave * 64 + lane : (int)threadIdx.x;
   const int wave_c0 = (wave % WAVES_C) * (NI * 16);
   const int wave_p0 = (wave / WAVES_C) * (NJ * 16);
   const int cq = (lane >> 4) * 4;
@@ -114,14 +118,14 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float xh = xf[r] * ka[r] + kb[r];
-            const float t = acc[i][j][r] * act_grad_from_in(xh * kg[r] + kt[r], p.mul.act, p.mul.slope);
+            const float t = (SCALED ? acc[i][j][r] * p.oscale : acc[i][j][r]) * act_grad_from_in(xh * kg[r] + kt[r], p.mul.act, p.mul.slope);
             if (pvalid[j]) { s1[r] += t; s2[r] += t * xh; }
             v[r] = ((c + r) < p.Cout) ? t : 0.f;
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float t = acc[i][j][r] + b4[r];
+            const float t = (SCALED ? acc[i][j][r] * p.oscale : acc[i][j][r]) + b4[r];
             if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
             v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
           }

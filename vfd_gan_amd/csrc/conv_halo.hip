@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(const HaloP p) {
     if (!row_q(r, qd, qh, qw)) return -1;
     return (((long long)(n * p.Do + qd * dd.so + dd.r) * p.Ho + qh * dh.so + dh.r) * p.Wo + qw * dw.so + dw.r) * p.e.Cop;
   };
-  conv_epilogue<bf16_t, 1, 4, NI, NJ, C::LDS, (DBG & 64) != 0>(smem, acc, p.e, n0, (int)(item & 0x7fffffff) + cls_id, out_offset,
+  conv_epilogue<bf16_t, 1, 4, NI, NJ, C::LDS, (DBG & 64) != 0, false>(smem, acc, p.e, n0, (int)(item & 0x7fffffff) + cls_id, out_offset,
                                              [&](int r) { int a_, b_, c_; return row_q(r, a_, b_, c_); });
 }
 

@@ -46,6 +46,8 @@ struct ConvP {
   DimClass dims[3][DIM_TAB];   // [d,h,w][output class r]: built on the host (make_dim_host), so that a workgroup's setup
                                // is scalar loads instead of ~15 integer divisions (one of them 64-bit) per dimension
   MulP mul;     // mul.src non-null: gradient hand-over in the epilogue (common.hpp)
+  const float* qscale_x;   // fp8 operands: device scalars the tensors were multiplied by when quantised (x_q = x * scale);
+  const float* qscale_w;   // the epilogue multiplies the accumulator by 1 / (scale_x * scale_w)
 };
 
 
@@ -115,6 +117,36 @@ template <> struct Mma<bf16_t> {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+template <> struct Mma<fp8_t> {
+  // one 128-byte row = 128 e4m3 = ONE v_mfma_f32_16x16x128_f8f6f4 per 16x16 tile (unscaled form: both block scales are the
+  // constant 0, which the compiler folds away): twice the cycles of the bf16 16x16x32 at four times the K, i.e. twice the
+  // FLOPs per clock, for the same LDS / DMA bytes per row as bf16.  Lane l holds K bytes [32 (l>>4), +32) of row l & 15
+  // (two 16-byte chunks: ck_tile's kABKPerLane = 32 / kABKLane = 4 map; checked with exact integer data, tests/test_fp8.py).
+  template <int NI, int NJ, int KSUB>
+  __device__ static __forceinline__ void step(const char* wt, const char* pt, int wrow0, int prow0, int lane,
+                                              f32x4 (&acc)[NI][NJ]) {
+    static_assert(KSUB == 2, "fp8 tiles use 128-byte rows");
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    const int r = lane & 15, q = lane >> 4;
+    // 8 registers per fragment: with all NI + NJ fragments resident the 16-wave tile (64 accumulator registers, 128 in
+    // all) spills; the A fragments stay, the B fragments pass through one register set (the 4 queued MFMAs of a B fragment
+    // run 256 cycles: the next fragment's LDS read hides behind them)
+    i32x8 a[NI], b;
+    auto ldfrag = [&](const char* base, int row) __attribute__((always_inline)) {
+      const uint4 lo = *reinterpret_cast<const uint4*>(base + lds_off<KSUB>(row, 2 * q));
+      const uint4 hi = *reinterpret_cast<const uint4*>(base + lds_off<KSUB>(row, 2 * q + 1));
+      return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a[i] = ldfrag(wt, wrow0 + i * 16 + r);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      b = ldfrag(pt, prow0 + j * 16 + r);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b, acc[i][j], 0, 0, 0, 0, 0, 0);
     }
   }
 };
@@ -377,6 +409,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   EpiP e;
   e.y = p.y; e.bias = p.bias; e.stats = p.stats; e.Cop = p.Cop; e.Cout = p.Cout; e.act = p.act; e.slope = p.slope;
   e.mul = p.mul;
+  e.oscale = 1.f;
+  if constexpr (std::is_same<T, fp8_t>::value) e.oscale = 1.f / (p.qscale_x[0] * p.qscale_w[0]);
   auto out_offset = [&](int r) -> long long {       // tile row -> element offset of the output pixel, or -1
     const long long m = m0 + r;
     if (m >= Mcls) return -1;
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     const int n = (int)q;
     return ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
   };
-  conv_epilogue<T, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES, BN>(smem, acc, e, n0, ptile + cls_id, out_offset,
+  conv_epilogue<typename OutOf<T>::type, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES, BN, std::is_same<T, fp8_t>::value>(smem, acc, e, n0, ptile + cls_id, out_offset,
                                                                                 [&](int r) { return m0 + r < Mcls; });
 }
 
@@ -445,7 +479,7 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
     }
   }
   ConvP q = p;
-  q.ksplit = p.mul.src != nullptr ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
+  q.ksplit = (p.mul.src != nullptr || std::is_same<T, fp8_t>::value) ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
@@ -463,11 +497,19 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
     const long long total = maxM * (p.Cop >> 3);
     long long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(conv_splitk_finish_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, q.ws, reinterpret_cast<T*>(p.y), p.bias,
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<typename OutOf<T>::type>, dim3((unsigned)nb), dim3(256), 0, st, q.ws, reinterpret_cast<typename OutOf<T>::type*>(p.y), p.bias,
                        maxM, p.Cout, p.Cop, q.ksplit, p.act, p.slope);
     VFD_CHECK_LAUNCH("conv_splitk_finish");
   }
   return VFD_OK;
+}
+
+// e4m3 operands: 128-byte rows only (one K = 128 MFMA per row): the 16-wave 256 x 256 tile, and 128 x 128 (4 waves) below
+// 129 channels
+int launch_fp8(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
+  if (p.mul.src != nullptr) { vfd_set_error("conv: no gradient hand-over with fp8 operands"); return VFD_EINVAL; }
+  if (p.Cout > 128) return launch_cfg<fp8_t, 4, 4, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);
+  return launch_cfg<fp8_t, 2, 2, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);
 }
 
 template <typename T>
@@ -505,7 +547,7 @@ int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_b
 
 int vfd_conv_check_desc(const vfd_conv_desc* d) {
   VFD_REQUIRE(d != nullptr, "conv: null descriptor");
-  VFD_REQUIRE(d->dtype == VFD_F32 || d->dtype == VFD_BF16, "conv: bad dtype %d", d->dtype);
+  VFD_REQUIRE(d->dtype == VFD_F32 || d->dtype == VFD_BF16 || d->dtype == VFD_FP8, "conv: bad dtype %d", d->dtype);
   VFD_REQUIRE(d->N > 0 && d->Di > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0, "conv: bad input dims");
   VFD_REQUIRE(d->Do > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "conv: bad output dims");
   VFD_REQUIRE(d->kd > 0 && d->kh > 0 && d->kw > 0 && d->sd > 0 && d->sh > 0 && d->sw > 0, "conv: bad filter/stride");
@@ -528,7 +570,7 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
 
 static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
                          size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream,
-                         const MulP& mul = no_mul()) {
+                         const MulP& mul = no_mul(), const float* qscale_x = nullptr, const float* qscale_w = nullptr) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
   vfd_conv_desc dn = *d_in;
   if (dn.transposed) {
@@ -548,7 +590,9 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
                 "conv: statistics buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) floats", stats_bytes);
     VFD_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y | (uintptr_t)ws) & 15) == 0, "conv: tensors must be 16-byte aligned");
   }
-  {
+  const bool fp8 = d->dtype == VFD_FP8;      // e4m3 operands, bf16 output: conv_igemm's 128-byte-row tiles only
+  if (fp8 && ws_query == nullptr) VFD_REQUIRE(qscale_x != nullptr && qscale_w != nullptr, "conv: fp8 operands need their scales (vfd_conv_forward_fp8)");
+  if (!fp8) {
     // thin-channel pyramid ends have their own kernels (conv_small.hip); they need no workspace
     const int h = mul.src != nullptr ? 0 : vfd_conv_small_try(d, x, packed, bias, y, stats, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
@@ -557,7 +601,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
       return VFD_OK;
     }
   }
-  {
+  if (!fp8) {
     const int h = vfd_conv_halo_try(d, x, packed, bias, y, stats, mul, ws_query != nullptr, as_stream(stream));
     if (h < 0) return VFD_ELAUNCH;
     if (h > 0) {
@@ -567,7 +611,8 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   }
   ConvP p;
   p.x = x; p.w = packed; p.y = y; p.bias = bias; p.stats = stats;
-  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = cpad(d->Cin);
+  p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Cip = fp8 ? cpad16(d->Cin) : cpad(d->Cin);
+  p.qscale_x = qscale_x; p.qscale_w = qscale_w;
   p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo; p.Cop = cpad(d->Cout); p.Cout = d->Cout;
   p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw;
   p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
@@ -599,6 +644,7 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
     maxM = (long long)d->N * qd * qh * qw;
   }
   hipStream_t st = as_stream(stream);
+  if (fp8) return launch_fp8(p, maxM, ncls, st, ws_bytes, ws_query);
   return d->dtype == VFD_BF16 ? launch<bf16_t>(p, maxM, ncls, st, ws_bytes, ws_query) : launch<float>(p, maxM, ncls, st, ws_bytes, ws_query);
 }
 
@@ -612,7 +658,11 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
   }
   int rc = vfd_conv_check_desc(&dn);
   if (rc != VFD_OK) return rc;
-  const char* t = dn.dtype == VFD_BF16 ? "bf16" : "f32";
+  const char* t = dn.dtype == VFD_BF16 ? "bf16" : dn.dtype == VFD_FP8 ? "fp8" : "f32";
+  if (dn.dtype == VFD_FP8) {
+    snprintf(buf, n, "conv_igemm<fp8,%s>", dn.Cout > 128 ? "256c_x_256p" : "128c_x_128p");
+    return VFD_OK;
+  }
   float dummy_stats;
   if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0 ? &dummy_stats : nullptr, true, nullptr) > 0) {
     snprintf(buf, n, "%s<%s>", cpad(dn.Cin) == 8 ? "conv_cin8" : "convt_thin", t);
@@ -638,6 +688,16 @@ extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t
 extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                                 float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
   return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, ws, ws_bytes, nullptr, stream);
+}
+
+// e4m3 operands (x: channels-last with CPAD16 channels, packed: vfd_pack_filter_fp8), bf16 output y = act(acc / (sx*sw) +
+// bias), optional BatchNorm statistics; scale_x / scale_w are DEVICE scalars (what the tensors were multiplied by when
+// quantised), read by the kernel, so that a captured step follows scales that change from step to step.
+extern "C" int vfd_conv_forward_fp8(const vfd_conv_desc* d, const void* x, const float* scale_x, const void* packed,
+                                    const float* scale_w, const float* bias, void* y, float* stats, size_t stats_bytes, void* stream) {
+  VFD_REQUIRE(d != nullptr && d->dtype == VFD_FP8, "conv_forward_fp8: descriptor dtype must be VFD_FP8");
+  VFD_REQUIRE(scale_x != nullptr && scale_w != nullptr, "conv_forward_fp8: null scale pointer");
+  return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, nullptr, 0, nullptr, stream, no_mul(), scale_x, scale_w);
 }
 
 extern "C" int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,

@@ -18,14 +18,47 @@ from ._lib import ConvDesc, check, dtype_code, load, ptr, stream
 _COMPUTE_DTYPE = torch.bfloat16
 
 
+_FP8 = [False]
+
+
 def set_compute_dtype(dt):
-    """Storage type of activations / packed filters: torch.bfloat16 (default, MFMA bf16) or torch.float32."""
+    """Storage type of activations / packed filters: torch.bfloat16 (default, MFMA bf16) or torch.float32; "fp8" = bf16
+    storage with e4m3 OPERANDS for the forward pass and the data gradient of every convolution wide enough for the fp8
+    tiles (BASELINE configs[4]; see set_fp8)."""
     global _COMPUTE_DTYPE
+    fp8 = isinstance(dt, str) and dt in ("fp8", "e4m3")
+    if fp8:
+        dt = torch.bfloat16
     if isinstance(dt, str):
         dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
               "float32": torch.float32}[dt]
     dtype_code(dt)
     _COMPUTE_DTYPE = dt
+    _FP8[0] = fp8
+
+
+def set_fp8(on):
+    """fp8 operand mode (bf16 activations only): a convolution with >= 64 input and > 128 output channels runs its forward
+    pass on v_mfma_f32_16x16x128_f8f6f4 with e4m3 copies of its input and filter (per-tensor current scaling: vfd_amax +
+    vfd_quantize_fp8 / vfd_pack_filter_fp8), and its data gradient likewise when the roles' channel counts allow; outputs,
+    BatchNorm, the filter gradient and the master weights stay bf16 / f32.  Returns the previous setting."""
+    prev = _FP8[0]
+    _FP8[0] = bool(on)
+    return prev
+
+
+def fp8_enabled():
+    return _FP8[0]
+
+
+_FP8_MIN_OUT = [129]     # tests lower it to 65 to drive the 128 x 128 fp8 tile through a whole step
+
+
+def _fp8_eligible(K_channels, out_channels, dt):
+    # more than 128 output channels: the 16-wave 256 x 256 fp8 tile (1.1-1.6 PFLOP/s on the ganomaly pyramid against
+    # 0.8-1.0 for bf16); the 4-wave 128 x 128 fp8 tile (<= 128 output channels) is no faster than the bf16 tiles of that
+    # range, so those layers stay bf16
+    return _FP8[0] and dt == torch.bfloat16 and K_channels >= 64 and out_channels >= _FP8_MIN_OUT[0]
 
 
 def get_compute_dtype():
@@ -451,11 +484,16 @@ class _Conv(torch.autograd.Function):
         dt = x.dtype
         T = k[0] * k[1] * k[2]
         A, B = (Cin, Cout) if transposed else (Cout, Cin)  # torch filter layout [A][B][T]
-        packed = _packed_filter(weight, dt, transpose_ab=bool(transposed), A=A, B=B, T=T)
-        out = torch.empty((N,) + tuple(out_dhw) + (cpad(Cout),), dtype=dt, device=x.device)
-        desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act, slope)
         b = bias.detach() if bias is not None else None
-        _conv_launch(desc, x, packed, b, out, stats)
+        if _fp8_eligible(Cin, Cout, dt):
+            xq, xs = _quantized(x, Cin)
+            wq, ws = _packed_filter_fp8(weight, bool(transposed), A, B, T)
+            out = conv_fp8(xq, xs, wq, ws, b, N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, act, slope, stats)
+        else:
+            packed = _packed_filter(weight, dt, transpose_ab=bool(transposed), A=A, B=B, T=T)
+            out = torch.empty((N,) + tuple(out_dhw) + (cpad(Cout),), dtype=dt, device=x.device)
+            desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt, act, slope)
+            _conv_launch(desc, x, packed, b, out, stats)
         ctx.geom = geom
         ctx.in_dhw = in_dhw
         ctx.has_bias = bias is not None
@@ -503,10 +541,15 @@ class _Conv(torch.autograd.Function):
         bias_done = False
         if ctx.needs_input_grad[0]:
             # data gradient = the opposite kind of convolution with the A/B-swapped filter packing
-            packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
-            gx = torch.empty_like(x)
-            desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
-            _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
+            if ctx.in_act is None and ctx.in_bn is None and _fp8_eligible(Cout, Cin, dt):
+                gq, gs = _quantized(gy, Cout)
+                wq, ws = _packed_filter_fp8(weight, not transposed, A, B, T)
+                gx = conv_fp8(gq, gs, wq, ws, None, N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed)
+            else:
+                packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
+                gx = torch.empty_like(x)
+                desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
+                _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
         if ctx.needs_input_grad[1]:
             desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
@@ -586,8 +629,109 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
 
 
 # ---------------------------------------------------------------------------------------------------------
+# fp8 operands (OCP e4m3fn, per-tensor current scaling; include/vfdgan_hip.h "fp8 operands")
+# ---------------------------------------------------------------------------------------------------------
+def cpad16(c):
+    return (c + 15) & ~15
+
+
+def quantize_fp8(t, C):
+    """Channels-last block `t` [..., CPAD(C)] (bf16 / f32) -> (uint8 tensor [..., CPAD16(C)] of e4m3 bytes, device scale):
+    q = e4m3(t * scale), scale = 448 / max|t| taken from the tensor itself."""
+    t = t.contiguous()
+    rows = t.numel() // t.shape[-1]
+    lib = load()
+    amax = torch.empty(1, dtype=torch.float32, device=t.device)
+    scale = torch.empty(1, dtype=torch.float32, device=t.device)
+    q = torch.empty(tuple(t.shape[:-1]) + (cpad16(C),), dtype=torch.uint8, device=t.device)
+    check(lib.vfd_amax(dtype_code(t.dtype), t.data_ptr(), rows, C, amax.data_ptr(), stream()), "amax")
+    check(lib.vfd_quantize_fp8(dtype_code(t.dtype), t.data_ptr(), q.data_ptr(), rows, C, amax.data_ptr(), scale.data_ptr(), stream()),
+          "quantize_fp8")
+    return q, scale
+
+
+def pack_filter_fp8(weight, transpose_ab, A, B, T):
+    """K-major e4m3 copy of a float32 filter [A][B][T] (vfd_pack_filter's index map, channels padded to 16) and its scale."""
+    w = weight.detach().contiguous().float()
+    R, Cc = (B, A) if transpose_ab else (A, B)
+    out = torch.empty((R, T, cpad16(Cc)), dtype=torch.uint8, device=w.device)
+    amax = torch.empty(1, dtype=torch.float32, device=w.device)
+    scale = torch.empty(1, dtype=torch.float32, device=w.device)
+    check(load().vfd_pack_filter_fp8(w.data_ptr(), out.data_ptr(), A, B, T, int(transpose_ab), amax.data_ptr(), scale.data_ptr(), stream()),
+          "pack_filter_fp8")
+    return out, scale
+
+
+def _quantized(t, C):
+    """e4m3 copy of a channels-last block, made once per tensor (a tensor with several consumers — netD's two forwards of the
+    same features, forward input re-used by nothing else — is quantised once)."""
+    hit = getattr(t, "_vfd_q", None)
+    if hit is not None and hit[2] == t._version:
+        return hit[0], hit[1]
+    q, scale = quantize_fp8(t, C)
+    try:
+        t._vfd_q = (q, scale, t._version)
+    except AttributeError:
+        pass
+    return q, scale
+
+
+def _packed_filter_fp8(weight, transpose_ab, A, B, T):
+    """Cached e4m3 K-major copy of a filter parameter + its scale (same freshness tag as _packed_filter; re-packed lazily:
+    amax + pack launches per filter and step)."""
+    cache = weight.__dict__.setdefault("_vfd_packed", {})
+    key = ("fp8", transpose_ab)
+    own = getattr(weight, "_vfd_epoch", None)
+    tag = (weight._version, _WEIGHT_EPOCH[0], own[0] if own is not None else 0, weight.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    w = weight.detach()
+    if not w.is_contiguous() or w.dtype != torch.float32:
+        w = w.contiguous().float()
+    R, Cc = (B, A) if transpose_ab else (A, B)
+    shape = (R, T, cpad16(Cc))
+    if hit is not None and tuple(hit[1].shape) == shape:
+        out, amax, scale = hit[1], hit[3], hit[2]
+    else:
+        out = torch.empty(shape, dtype=torch.uint8, device=w.device)
+        amax = torch.empty(1, dtype=torch.float32, device=w.device)
+        scale = torch.empty(1, dtype=torch.float32, device=w.device)
+    check(load().vfd_pack_filter_fp8(w.data_ptr(), out.data_ptr(), A, B, T, int(transpose_ab), amax.data_ptr(), scale.data_ptr(), stream()),
+          "pack_filter_fp8")
+    cache[key] = [tag, out, scale, amax]
+    return out, scale
+
+
+def conv_fp8(xq, xscale, wq, wscale, bias, N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, act=_lib.ACT_NONE, slope=0.0, stats=None):
+    """y (bf16, [N, *out_dhw, CPAD(Cout)]) = act(conv(xq, wq) / (xscale * wscale) + bias) on the fp8 MFMA path."""
+    desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, torch.bfloat16, act, slope)
+    desc.dtype = _lib.FP8
+    y = torch.empty((N,) + tuple(out_dhw) + (cpad(Cout),), dtype=torch.bfloat16, device=xq.device)
+    timer = _TIMER[0]
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(load().vfd_conv_forward_fp8(ctypes.byref(desc), xq.data_ptr(), xscale.data_ptr(), wq.data_ptr(), wscale.data_ptr(), ptr(bias),
+                                      y.data_ptr(), ptr(stats), stats.numel() * 4 if stats is not None else 0, stream()), "conv_forward_fp8")
+    if timer is not None:
+        e1.record()
+        timer.records.append((_conv_kernel_name(desc, stats), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
 # BatchNorm (train mode) + activation
 # ---------------------------------------------------------------------------------------------------------
+_LAST_BN_STATS = [None]      # (mean, rstd, rows) of the most recent training-mode bn_act (nn._BatchNormMixin keeps it on request)
+
+
+def bn_running_update(mean, rstd, rows, C, running_mean, running_var, eps, momentum, num_batches_tracked):
+    """The running-statistics side effect of one more training-mode forward with the same batch statistics."""
+    check(load().vfd_bn_running_update(mean.data_ptr(), rstd.data_ptr(), rows, C, float(eps), float(momentum), ptr(running_mean),
+                                       ptr(running_var), ptr(num_batches_tracked), stream()), "bn_running_update")
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, token, conv_bias=None,
@@ -615,6 +759,7 @@ class _BnAct(torch.autograd.Function):
             check(lib.vfd_bn_act_forward(dtc, x.data_ptr(), y.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), ptr(g_),
                                          ptr(b_), act, slope, stream()), "bn_act_forward")
         ctx.meta = (rows, C, act, slope)
+        _LAST_BN_STATS[0] = (mean, rstd, rows)
         ctx.token = token
         ctx.conv_bias = None
         if (token is not None and bias_token is not None and conv_bias is not None and conv_bias.requires_grad

@@ -43,7 +43,7 @@ class Args():
                                  help='Use AutoEncoder on c2plus1d net as Generator (unsupported: broken in the reference)')
 
         # build-only switches
-        self.parser.add_argument('--dtype', default="bf16", choices=["bf16", "f32"],
+        self.parser.add_argument('--dtype', default="bf16", choices=["bf16", "f32", "fp8"],
                                  help='activation/filter storage type of the HIP kernels (accumulation is always f32)')
         self.parser.add_argument('--data', default="synthetic", choices=["synthetic"],
                                  help='clip source (video decode is out of scope, SURVEY.md section 2 row 9)')

@@ -224,7 +224,12 @@ class Ganomaly(GANBaseModel):
         self.fake, self.latent_i, self.latent_o = self.netg(self.x)
 
     def forward_d(self):
+        bns = [m for m in self.netd.modules() if isinstance(m, hnn._BNS)]
+        for m in bns:
+            m._keep_batch_stats = True
         self.pred_real, self.feat_real = self.netd(self.x)
+        for m in bns:
+            m._keep_batch_stats = False       # (their _batch_stats now describe netd(x): used by backward_g)
         self.pred_fake, self.feat_fake = self.netd(self.fake.detach())
 
     def backward_g(self, join=True):
@@ -235,7 +240,14 @@ class Ganomaly(GANBaseModel):
             p.requires_grad_(False)
         self.reducer_d.enabled = False
         try:
-            self.err_g_adv = self.l_adv(self.netd(self.x)[1], self.netd(self.fake)[1])
+            # The reference evaluates netd(input) a second time here (models/ganomaly.py:485).  netD's weights have not
+            # changed since forward_d and the input is the same, so the features are forward_d's feat_real bit for bit; the
+            # only other effect of that forward, one more BatchNorm running-statistics update with the same batch statistics,
+            # is applied directly.  (netd(fake) must be evaluated again: this time the gradient flows into netG.)
+            for m in self.netd.modules():
+                if isinstance(m, hnn._BNS) and m.training:
+                    m.repeat_running_update()
+            self.err_g_adv = self.l_adv(self.feat_real.detach(), self.netd(self.fake)[1])
             self.err_g_con = self.l_con(self.fake, self.x)
             self.err_g_enc = self.l_enc(self.latent_o, self.latent_i)
             self.err_g = self.err_g_adv * self.opt.w_adv + \

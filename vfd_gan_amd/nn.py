@@ -103,8 +103,19 @@ class _BatchNormMixin:
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         nbt = self.num_batches_tracked if self.track_running_stats else None      # += 1 inside the statistics kernel
-        return F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums,
-                        conv_bias, bias_token)
+        y = F.bn_act(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums,
+                     conv_bias, bias_token)
+        if getattr(self, "_keep_batch_stats", False):
+            self._batch_stats = F._LAST_BN_STATS[0]      # (mean, rstd, rows): see repeat_running_update
+        return y
+
+    def repeat_running_update(self):
+        """Apply the running-statistics update of the last training-mode forward once more (a repeated forward on the same
+        input and weights, without the forward)."""
+        mean, rstd, rows = self._batch_stats
+        if self.track_running_stats:
+            F.bn_running_update(mean, rstd, rows, self.num_features, self.running_mean, self.running_var, self.eps, self.momentum,
+                                self.num_batches_tracked)
 
 
 class BatchNorm3d(_BatchNormMixin, tnn.BatchNorm3d):
