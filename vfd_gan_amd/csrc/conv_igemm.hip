@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   }
 
   const int cq = (lane >> 4) * 4;
-  if (p.ksplit > 1) {
+  if (!std::is_same<T, fp8_t>::value && p.ksplit > 1) {      // (fp8 tiles never split K: keeps `lane` from living across their main loop)
     // split-K: raw partial sums, [ksplit][M][Cop] float32; bias / activation / store happen in conv_splitk_finish
     float* slab = p.ws + (size_t)ksl * (size_t)Mcls * p.Cop;
 #pragma unroll

@@ -498,6 +498,7 @@ class _Conv(torch.autograd.Function):
         ctx.in_dhw = in_dhw
         ctx.has_bias = bias is not None
         ctx.bias_param = bias
+        ctx.weight_param = weight
         # activation-gradient hand-over (nn.run_fused only, where the producer's output has exactly one consumer):
         # `in_act` is the token of the conv+activation that produced x; claiming it means THIS layer's data gradient is
         # delivered already multiplied by act'(x) (vfd_conv_forward_mul) and the producer skips its act_backward pass.
@@ -539,7 +540,8 @@ class _Conv(torch.autograd.Function):
         A, B = (Cin, Cout) if transposed else (Cout, Cin)
         gx = gw = gb = None
         bias_done = False
-        if ctx.needs_input_grad[0]:
+        frozen = _frozen(ctx.weight_param)
+        if ctx.needs_input_grad[0] and x.data_ptr() not in _SKIP_INPUT_GRAD:
             # data gradient = the opposite kind of convolution with the A/B-swapped filter packing
             if ctx.in_act is None and ctx.in_bn is None and _fp8_eligible(Cout, Cin, dt):
                 gq, gs = _quantized(gy, Cout)
@@ -550,7 +552,7 @@ class _Conv(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
                 _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not frozen:
             desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
             nbytes = ctypes.c_size_t()
@@ -581,7 +583,7 @@ class _Conv(torch.autograd.Function):
             else:
                 gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
                 check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
-        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done and not frozen:
             bias = ctx.bias_param
             direct = _direct_grad(bias)
             bws = _workspace(lib.vfd_bias_grad_workspace(Cout), x.device)
@@ -723,6 +725,34 @@ def conv_fp8(xq, xscale, wq, wscale, bias, N, in_dhw, Cin, out_dhw, Cout, k, s, 
 # ---------------------------------------------------------------------------------------------------------
 # BatchNorm (train mode) + activation
 # ---------------------------------------------------------------------------------------------------------
+# ---- one forward, two backward passes (ganomaly: netd(fake) serves backward_g and backward_d) -------------------------------
+# A parameter marked `_vfd_frozen` receives no gradient work in a backward pass although it required grad when the graph
+# was built (the pass that runs with the net "frozen"); inputs whose data_ptr is in _SKIP_INPUT_GRAD get no data gradient;
+# sum pools created inside collect_pools() are listed so that they can be zeroed between the two passes.
+_SKIP_INPUT_GRAD = set()
+_POOL_SINK = [None]
+
+
+def _frozen(prm):
+    return prm is not None and getattr(prm, "_vfd_frozen", False)
+
+
+class collect_pools:
+    def __enter__(self):
+        self.prev, self.pools = _POOL_SINK[0], []
+        _POOL_SINK[0] = self.pools
+        return self.pools
+
+    def __exit__(self, *exc):
+        _POOL_SINK[0] = self.prev
+        return False
+
+
+def register_pool(t):
+    if _POOL_SINK[0] is not None:
+        _POOL_SINK[0].append(t)
+
+
 _LAST_BN_STATS = [None]      # (mean, rstd, rows) of the most recent training-mode bn_act (nn._BatchNormMixin keeps it on request)
 
 
@@ -786,8 +816,9 @@ class _BnAct(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = _workspace(lib.vfd_bn_workspace(rows, C), dev)
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
-        dg_acc = _direct_grad(gamma) if ctx.needs_input_grad[1] else None     # a frozen net's gradients stay untouched
-        db_acc = _direct_grad(beta) if ctx.needs_input_grad[2] else None
+        frozen = _frozen(gamma) or _frozen(beta)
+        dg_acc = _direct_grad(gamma) if (ctx.needs_input_grad[1] and not frozen) else None     # a frozen net's gradients stay untouched
+        db_acc = _direct_grad(beta) if (ctx.needs_input_grad[2] and not frozen) else None
         nret = (None,) * 12
         cs_acc = ctx.conv_bias
         if ctx.token is not None and ctx.token["claimed"]:
@@ -798,21 +829,21 @@ class _BnAct(torch.autograd.Function):
                                                  dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ptr(cs_acc),
                                                  stream()),
                   "bn_backward_apply_sums")
-            return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
-                    dbeta if (beta is not None and db_acc is None) else None) + nret
+            return (dx, dgamma if (gamma is not None and dg_acc is None and not frozen) else None,
+                    dbeta if (beta is not None and db_acc is None and not frozen) else None) + nret
         if ctx.token is not None:
             # unclaimed, but a zeroed sums buffer is at hand: reduce into it with atomics, fold in the apply pass (two launches)
             check(lib.vfd_bn_act_backward_sums(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                                mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope,
                                                ctx.token["sums"].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc),
                                                ptr(db_acc), ptr(cs_acc), stream()), "bn_act_backward_sums")
-            return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
-                    dbeta if (beta is not None and db_acc is None) else None) + nret
+            return (dx, dgamma if (gamma is not None and dg_acc is None and not frozen) else None,
+                    dbeta if (beta is not None and db_acc is None and not frozen) else None) + nret
         check(lib.vfd_bn_act_backward(dtype_code(x.dtype), x.data_ptr(), gy.data_ptr(), dx.data_ptr(), rows, C,
                                       mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope, dgamma.data_ptr(),
                                       dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc), ws.data_ptr(), stream()), "bn_act_backward")
-        return (dx, dgamma if (gamma is not None and dg_acc is None) else None,
-                dbeta if (beta is not None and db_acc is None) else None) + nret
+        return (dx, dgamma if (gamma is not None and dg_acc is None and not frozen) else None,
+                dbeta if (beta is not None and db_acc is None and not frozen) else None) + nret
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,

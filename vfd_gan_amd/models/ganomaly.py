@@ -224,39 +224,46 @@ class Ganomaly(GANBaseModel):
         self.fake, self.latent_i, self.latent_o = self.netg(self.x)
 
     def forward_d(self):
+        """netd(input) and netd(fake), ONCE each.  The reference evaluates both a second time inside backward_g
+        (models/ganomaly.py:485) with unchanged weights and inputs: identical values.  Here the first results serve both
+        backward passes — netd(fake) is kept attached to netG's graph and back-propagated twice (into netG with netD frozen,
+        then into netD) — and the only other effect of the repeated forwards, a second BatchNorm running-statistics update
+        with the same batch statistics, is applied directly (backward_g), in the reference's order."""
         bns = [m for m in self.netd.modules() if isinstance(m, hnn._BNS)]
         for m in bns:
             m._keep_batch_stats = True
         self.pred_real, self.feat_real = self.netd(self.x)
+        stats_real = [(m, m._batch_stats) for m in bns if m.training]
+        with F.collect_pools() as self._dfake_pools:
+            self.pred_fake, self.feat_fake = self.netd(self.fake)
+        stats_fake = [(m, m._batch_stats) for m in bns if m.training]
         for m in bns:
-            m._keep_batch_stats = False       # (their _batch_stats now describe netd(x): used by backward_g)
-        self.pred_fake, self.feat_fake = self.netd(self.fake.detach())
+            m._keep_batch_stats = False
+        self._d_repeat_stats = stats_real + stats_fake
 
     def backward_g(self, join=True):
         # The reference lets this backward also deposit gradients into netD's parameters and then discards them
         # (optimizer_d.zero_grad() at :515 runs before they are ever used).  Freezing netD here skips exactly that
         # discarded filter-gradient work; everything that survives the step is unchanged.
-        for p in self.netd.parameters():
-            p.requires_grad_(False)
+        netd_params = list(self.netd.parameters())
+        for p in netd_params:
+            p._vfd_frozen = True
         self.reducer_d.enabled = False
         try:
-            # The reference evaluates netd(input) a second time here (models/ganomaly.py:485).  netD's weights have not
-            # changed since forward_d and the input is the same, so the features are forward_d's feat_real bit for bit; the
-            # only other effect of that forward, one more BatchNorm running-statistics update with the same batch statistics,
-            # is applied directly.  (netd(fake) must be evaluated again: this time the gradient flows into netG.)
-            for m in self.netd.modules():
-                if isinstance(m, hnn._BNS) and m.training:
-                    m.repeat_running_update()
-            self.err_g_adv = self.l_adv(self.feat_real.detach(), self.netd(self.fake)[1])
+            for m, st in self._d_repeat_stats:      # the BatchNorm side effect of the reference's repeated netd(input), netd(fake)
+                m._batch_stats = st
+                m.repeat_running_update()
+            self.err_g_adv = self.l_adv(self.feat_real.detach(), self.feat_fake)
             self.err_g_con = self.l_con(self.fake, self.x)
             self.err_g_enc = self.l_enc(self.latent_o, self.latent_i)
             self.err_g = self.err_g_adv * self.opt.w_adv + \
                          self.err_g_con * self.opt.w_con + \
                          self.err_g_enc * self.opt.w_enc
-            self.err_g.backward()
+            # netd(fake)'s graph is walked again by backward_d: keep it
+            torch.autograd.backward(self.err_g, inputs=[p for p in self.netg.parameters() if p.requires_grad], retain_graph=True)
         finally:
-            for p in self.netd.parameters():
-                p.requires_grad_(True)
+            for p in netd_params:
+                p._vfd_frozen = False
             self.reducer_d.enabled = True
         if join:
             self.reducer_g.finish()
@@ -265,7 +272,14 @@ class Ganomaly(GANBaseModel):
         self.err_d_real = self.l_bce(self.pred_real, self.real_label)
         self.err_d_fake = self.l_bce(self.pred_fake, self.fake_label)
         self.err_d = (self.err_d_real + self.err_d_fake) * 0.5
-        self.err_d.backward()
+        for pool in self._dfake_pools:          # BatchNorm / bias sum buffers of netd(fake): second walk of that graph
+            pool.zero_()
+        skip = self.fake.t.data_ptr()           # ... which stops at netD's first layer (the reference detaches fake here)
+        F._SKIP_INPUT_GRAD.add(skip)
+        try:
+            torch.autograd.backward(self.err_d, inputs=[p for p in self.netd.parameters() if p.requires_grad])
+        finally:
+            F._SKIP_INPUT_GRAD.discard(skip)
         if join:
             self.reducer_d.finish()
 

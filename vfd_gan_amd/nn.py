@@ -218,6 +218,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
                 need += F.stats_buffer_numel(m.num_features)      # backward sums (every training BatchNorm)
         if need:
             pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
+            F.register_pool(pool)
 
     def take(C):
         nonlocal pool_off
