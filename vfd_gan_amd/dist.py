@@ -63,6 +63,11 @@ def broadcast_module(module, src=0):
             tdist.broadcast(t.data, src=src)
 
 
+def _join_side():
+    from . import functional as F      # filter gradients issued on the side stream must have landed (functional._SIDE)
+    F.join_side_stream()
+
+
 def make_buckets(slices, bucket_elems):
     """Group consecutive (offset, numel) parameter slices — walked in REVERSE registration order, which is roughly
     the order gradients become ready — into contiguous [lo, hi) ranges of about `bucket_elems` elements.
@@ -128,6 +133,7 @@ class GradReducer:
         self.arm(1)
 
     def _launch(self, b):
+        _join_side()
         if self.launched[b]:
             return
         self.launched[b] = True
@@ -150,6 +156,7 @@ class GradReducer:
         graph replay, no autograd hook fires).  RCCL's stream waits for the work already queued on the current stream
         and the current stream does NOT wait for RCCL: whatever is launched next (the other net's backward graph) runs
         beside the collective.  join() makes the current stream wait."""
+        _join_side()
         for b in range(len(self.buckets)):
             self.launched[b] = False
             self._launch(b)
@@ -161,12 +168,14 @@ class GradReducer:
 
     def reduce_all(self):
         """All buckets now, and wait (blocking form of reduce_async + join)."""
+        _join_side()
         self.reduce_async()
         self.join()
 
     def finish(self):
         """Launch whatever has not been launched (parameters that received no gradient), wait for all buckets
         (the current stream waits; the host does not block with RCCL), and re-arm for the next backward."""
+        _join_side()
         for b in range(len(self.buckets)):
             self._launch(b)
         self.join()

@@ -6,6 +6,7 @@ libvfdgan_hip.so on torch's current stream.  Tensors that flow between ops are c
 wrapped in :class:`ClTensor`, which remembers the logical channel count.  PyTorch supplies device memory,
 streams and the autograd tape; no arithmetic of the hot path is done by torch operators.
 """
+import contextlib
 import ctypes
 import weakref
 import os
@@ -90,6 +91,32 @@ def _workspace(nbytes, device):
     if _POISON_WS[0] and ws.numel():
         ws.fill_(0xFF)          # 0xFFFFFFFF = NaN as float32; 0xFFFF = NaN as bfloat16
     return ws
+
+
+# ---- filter gradients on a side stream ----------------------------------------------------------------------------------
+# A layer's filter gradient (conv_wgrad + wgrad_reduce: MFMA-bound, needed only by the optimiser) is independent of
+# everything that follows it in the backward pass, which continues with the HBM-bound BatchNorm passes of the layer
+# below: issued on a second stream the two can share the CUs.  The launch stream waits for the side stream before
+# anything reads the gradients (join_side_stream: optimiser step, gradient reduction, end of a captured phase).
+_SIDE = {"on": bool(int(os.environ.get("VFD_SIDE_WGRAD", "0") or 0)), "stream": None, "dirty": False}
+
+
+def set_side_wgrad(on):
+    prev = _SIDE["on"]
+    _SIDE["on"] = bool(on)
+    return prev
+
+
+def _side_stream(device):
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream(device)
+    return _SIDE["stream"]
+
+
+def join_side_stream():
+    if _SIDE["dirty"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["dirty"] = False
 
 
 def stats_buffer_numel(C):
@@ -557,32 +584,39 @@ class _Conv(torch.autograd.Function):
             nsplit = ctypes.c_int32()
             nbytes = ctypes.c_size_t()
             check(lib.vfd_wgrad_workspace(ctypes.byref(desc), ctypes.byref(nsplit), ctypes.byref(nbytes)), "wgrad_workspace")
-            ws = _workspace(nbytes.value, x.device)
             timer = _TIMER[0]
-            if timer is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            check(lib.vfd_conv_wgrad(ctypes.byref(desc), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, stream()),
-                  "conv_wgrad")
-            if timer is not None:
-                e1.record()
-                buf = ctypes.create_string_buffer(64)
-                check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64), "wgrad_kernel_name")
-                timer.records.append((buf.value.decode(), _conv_flops(desc), e0, e1, _geom_str(desc)))
             direct = _direct_grad(weight)
             tok = ctx.bias_token
             bdirect = _direct_grad(ctx.bias_param) if (tok is not None and tok["taken"] and ctx.has_bias and ctx.needs_input_grad[2]) else None
-            if direct is not None and bdirect is not None:
-                # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias gradient)
-                # in replica rows: folded by the same launch
-                check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
-                                                bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
-                bias_done = True
-            elif direct is not None:
-                check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
-            else:
-                gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
-                check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
+            side = _side_stream(x.device) if (_SIDE["on"] and direct is not None and timer is None) else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())      # x, gy (and the bias sums) are products of the launch stream
+                for t in (x, gy) + ((tok["rep"],) if bdirect is not None else ()):
+                    t.record_stream(side)
+                _SIDE["dirty"] = True
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ws = _workspace(nbytes.value, x.device)
+                if timer is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                check(lib.vfd_conv_wgrad(ctypes.byref(desc), x.data_ptr(), gy.data_ptr(), ws.data_ptr(), nbytes.value, stream()),
+                      "conv_wgrad")
+                if timer is not None:
+                    e1.record()
+                    buf = ctypes.create_string_buffer(64)
+                    check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64), "wgrad_kernel_name")
+                    timer.records.append((buf.value.decode(), _conv_flops(desc), e0, e1, _geom_str(desc)))
+                if direct is not None and bdirect is not None:
+                    # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias
+                    # gradient) in replica rows: folded by the same launch
+                    check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
+                                                    bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
+                    bias_done = True
+                elif direct is not None:
+                    check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
+                else:
+                    gw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                    check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), gw.data_ptr(), 0.0, stream()), "wgrad_reduce")
         if ctx.has_bias and ctx.needs_input_grad[2] and not bias_done and not frozen:
             bias = ctx.bias_param
             direct = _direct_grad(bias)

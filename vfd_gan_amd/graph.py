@@ -73,6 +73,7 @@ class GraphedStep:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pool):
                         obj()
+                        F.join_side_stream()      # a side stream forked inside the capture must rejoin before it ends
                     pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool
                     self.program.append((kind, obj, g))
                 else:

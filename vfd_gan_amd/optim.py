@@ -68,6 +68,7 @@ class Adam(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure")
+        F.join_side_stream()         # filter gradients issued on the side stream (functional._SIDE) land in the arena first
         g = self.param_groups[0]
         self._step += 1      # host mirror; the kernel uses the device counter so a captured step can be replayed
         b1, b2 = g["betas"]
