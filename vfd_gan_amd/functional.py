@@ -98,7 +98,8 @@ def _workspace(nbytes, device):
 # everything that follows it in the backward pass, which continues with the HBM-bound BatchNorm passes of the layer
 # below: issued on a second stream the two can share the CUs.  The launch stream waits for the side stream before
 # anything reads the gradients (join_side_stream: optimiser step, gradient reduction, end of a captured phase).
-_SIDE = {"on": bool(int(os.environ.get("VFD_SIDE_WGRAD", "0") or 0)), "stream": None, "dirty": False}
+# Measured (graph replay): mygan 56.4 -> 54.3 ms, ganomaly 11.33 -> 11.24, anogan unchanged.  VFD_SIDE_WGRAD=0 turns it off.
+_SIDE = {"on": bool(int(os.environ.get("VFD_SIDE_WGRAD", "1") or 0)), "stream": None, "dirty": False}
 
 
 def set_side_wgrad(on):
