@@ -321,7 +321,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": traffic,
                                "launches_per_step": d["launches"] // timer_steps,
-                               "timed_in": "eager pass after the timed region, stream kept GPU-bound by a device-side delay",
+                               "timed_in": "eager single-stream pass after the timed region, stream kept GPU-bound by a device-side delay; rocprofv3 cross-check: profiles/r02_<model>_kernel_stats_single_stream.csv",
                                "avg_launch_us": round(net_us, 2), "avg_launch_us_raw_events": round(raw_us, 2),
                                "event_pair_overhead_us": round(event_overhead_us, 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}

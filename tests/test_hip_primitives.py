@@ -453,3 +453,69 @@ def test_adam_matches_torch(dev):
         o_hip.step()
     for a, b in zip(mine, ref):
         assert relerr(a, b) < 1e-6
+
+
+def test_bn_running_update_repeats_the_forward_side_effect(dev):
+    """vfd_bn_running_update(mean, rstd) == the running-statistics update of one more training-mode forward on the same batch
+    (torch.nn.BatchNorm2d run twice on identical input): what ganomaly's backward_g applies instead of repeating netd(x)."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F
+    torch.manual_seed(3)
+    x = _rand((6, 20, 9, 7), 41) * 2.0 + 0.7
+    ref = torch.nn.BatchNorm2d(20)
+    ref.train()
+    ref(x)
+    ref(x)
+    mine = vnn.BatchNorm2d(20).to(dev)
+    mine.train()
+    mine._keep_batch_stats = True
+    mine(F.to_cl(x.to(dev), torch.float32))
+    mine.repeat_running_update()
+    torch.cuda.synchronize()
+    assert relerr(mine.running_mean, ref.running_mean) < 1e-6
+    assert relerr(mine.running_var, ref.running_var) < 1e-6
+    assert int(mine.num_batches_tracked.item()) == 2
+
+
+def test_pack_filters_batched_equals_single(dev):
+    """vfd_pack_filters (every filter copy of an optimiser in one launch, device job table) == vfd_pack_filter per filter:
+    checked through the optimiser hook (functional.repack_owned) on filters of assorted shapes, both orientations."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F, optim
+    torch.manual_seed(9)
+    net = vnn.Sequential(vnn.Conv2d(5, 72, 4, 2, 1, bias=False), vnn.LeakyReLU(0.2), vnn.Conv3d(72, 40, (1, 3, 3), 1, (0, 1, 1)),
+                         vnn.LeakyReLU(0.2), vnn.ConvTranspose2d(40, 9, 4, 2, 1, bias=False)).to(dev)
+    opt = optim.Adam(net.parameters(), lr=1e-2)
+    x = F.to_cl(_rand((2, 5, 12, 12), 5).to(dev).requires_grad_(), torch.bfloat16)
+
+    def step():
+        opt.zero_grad()
+        y = x
+        for m in net:
+            y = m(y) if not isinstance(m, vnn.Conv3d) else F.ClTensor(m(F.ClTensor(y.t, y.C, 3)).t, 40, 2)
+        y.to_torch().float().pow(2).mean().backward()
+        opt.step()
+    step()          # first step: copies packed lazily, registered, table built
+    step()          # second step: all copies re-packed by the batched launch after the update
+    torch.cuda.synchronize()
+    n = 0
+    for prm in net.parameters():
+        for key, ent in prm.__dict__.get("_vfd_packed", {}).items():
+            if key[0] == "fp8":
+                continue
+            dt, tr = key
+            batched = ent[1].clone()
+            A, B = prm.shape[0], prm.shape[1]
+            T = prm[0, 0].numel()
+            single = torch.empty_like(batched)
+            _lib_check(F.load().vfd_pack_filter(F.dtype_code(dt), prm.detach().contiguous().data_ptr(), single.data_ptr(), A, B, T, int(tr),
+                                                F.stream()))
+            torch.cuda.synchronize()
+            assert torch.equal(batched, single), (tuple(prm.shape), key)
+            n += 1
+    assert n >= 5        # forward copies of 3 filters + data-gradient copies of the last 2
+
+
+def _lib_check(rc):
+    from vfd_gan_amd._lib import check
+    check(rc, "pack_filter")
