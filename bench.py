@@ -274,9 +274,18 @@ def main():
     if rank == 0:
         clips_s = world * a.batch * a.steps / elapsed
         peak = MFMA_PEAK_F32_TFLOPS if a.dtype == "f32" else MFMA_PEAK_BF16_TFLOPS      # (fp8 mode: priced against bf16, most FLOPs stay bf16)
-        names = {"ganomaly": "ganomaly 16x%d x%d %s batch=%d clips/GPU (BASELINE.json configs[1]): frames folded to (%d,3,%d,%d), "
-                             "generalised pyramid 112-56-28-14-7, nz=100 ngf=64, full optimize_params (G fwd, 4 D fwd, backward_g, "
-                             "Adam, backward_d, Adam)" % (a.isize, a.isize, a.dtype, a.batch, a.batch * a.nfr, a.isize, a.isize),
+        pyr, c_ = [], a.isize
+        while c_ >= 8 and c_ % 2 == 0 and (not pyr or pyr[-1] > 7):
+            pyr.append(c_)
+            c_ //= 2
+        if c_ not in pyr:
+            pyr.append(c_)
+        pyr = "-".join(str(v) for v in pyr)
+        gname = ("ganomaly %dx%dx%d %s batch=%d clips/GPU (BASELINE.json configs[%s]): frames folded to (%d,3,%d,%d), generalised pyramid %s, "
+                 "nz=100 ngf=64, full optimize_params (G fwd, D fwd on input and on fake, backward_g, Adam, backward_d, Adam)"
+                 % (a.nfr, a.isize, a.isize, a.dtype, a.batch, "1" if (a.isize, a.nfr) == (112, 16) else "4 geometry" if a.isize == 224 else "-",
+                    a.batch * a.nfr, a.isize, a.isize, pyr))
+        names = {"ganomaly": gname,
                  "anogan": "anogan 16x%dx%d %s batch=%d clips/GPU (BASELINE.json configs[2]): 3-D conv NetG (seed volume 512x2x%dx%d) / "
                            "NetD, full optimize_params (D on real, G fwd, D on fake, Adam(D), D on G(z), Adam(G))"
                            % (a.isize, a.isize, a.dtype, a.batch, a.isize // 8, a.isize // 8),
