@@ -50,16 +50,11 @@ class Args():
         self.parser.add_argument('--steps_per_epoch', default=8, type=int, help='synthetic batches per epoch')
 
     def parse(self, argv=None):
-        self.args = self.parser.parse_args(argv)
-
-        str_ids = self.args.gpu.split(',')
-        self.args.gpu = []
-        for str_id in str_ids:
-            id = int(str_id)
-            if id >= 0:
-                self.args.gpu.append(id)
-
-        if torch.cuda.is_available() and self.args.gpu:
-            torch.cuda.set_device(self.args.gpu[0] if torch.cuda.device_count() > self.args.gpu[0] else 0)
-
-        return self.args
+        ns = self.parser.parse_args(argv)
+        # "--gpu 0,1" -> [0, 1]; negative entries mean "no device" and are dropped (reference lib/args.py:44-49)
+        ns.gpu = [g for g in (int(tok) for tok in ns.gpu.split(',')) if g >= 0]
+        if ns.gpu and torch.cuda.is_available():
+            first = ns.gpu[0]
+            torch.cuda.set_device(first if first < torch.cuda.device_count() else 0)
+        self.args = ns
+        return ns
