@@ -106,3 +106,24 @@ def anogan_test(netg, netd, batches, zs):
             predicts.append(predict.permute(0, 2, 3, 4, 1).numpy())
     return ({"gen_loss": float(np.mean(gen_l)), "dis_loss_real": float(np.mean(dr)), "dis_loss_fake": float(np.mean(df))},
             scores(np.stack(gts), np.stack(predicts)))
+
+
+def ganomaly_test(netg, batches, fold):
+    """models/ganomaly.py:332-406: per test sample the anomaly score mean((latent_i - latent_o)^2) over the nz latent
+    channels (:370-372), min-max scaled over the whole test set (:396), ROC AUC against the labels (:398).  The reference
+    does NOT switch netg to eval mode here (no .eval() in the file): BatchNorm normalises with the statistics of each test
+    batch and keeps updating its running statistics, under torch.no_grad().  `fold`: clip block -> frames (the 4-tuple clip
+    contract of lib/train_gan.py:69 in front of the 2-D nets); every frame carries its clip's label."""
+    an, lab = [], []
+    with torch.no_grad():
+        for (inp, real, gt, lb) in batches:
+            x = fold(inp)
+            fake, latent_i, latent_o = netg(x)
+            err = torch.mean(torch.pow(latent_i - latent_o, 2), dim=1)                  # :372
+            an.append(err.reshape(err.size(0)))
+            lab.append(lb.reshape(-1).repeat_interleave(x.shape[0] // lb.numel()))
+    an = torch.cat(an)
+    lab = torch.cat(lab).long()
+    an = (an - an.min()) / (an.max() - an.min())                                        # :396
+    fpr, tpr, _ = roc_curve(lab.numpy(), an.numpy())
+    return {"AUC": float(auc(fpr, tpr)), "an_scores": an.numpy(), "gt_labels": lab.numpy()}

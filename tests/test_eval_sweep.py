@@ -151,6 +151,38 @@ def test_mygan_test_sweep(dev, tmp_path):
     assert model.netg.training and int(model.netg.dconv1.bn.num_batches_tracked) == int(og.dconv1.bn.num_batches_tracked) == 2
 
 
+def test_ganomaly_test_sweep(dev, tmp_path):
+    """Ganomaly.test() (reference models/ganomaly.py:332-406: anomaly score per frame, min-max scaled, ROC AUC; BatchNorm in
+    TRAIN mode under no_grad, as there) against the oracle's restatement on the same weights and clips, float32."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.lib.data import synthetic_batch
+    from vfd_gan_amd.models import ganomaly as HG
+    from vfd_oracle import ganomaly as OG
+    from vfd_oracle.evalsweep import ganomaly_test
+    from vfd_oracle.weights import fill_module
+    F.set_compute_dtype(torch.float32)
+    B, T, S, ngf = 2, 3, 32, 16
+    opt = OG.make_opt(isize=S, ngf=ngf)
+    og = fill_module(OG.NetG(opt), 17)
+    batches = []
+    for i in range(3):
+        inp, real, gt, lb = synthetic_batch(B, T, S, 3, seed=900 + i)
+        batches.append((inp, real, gt, torch.tensor([i % 2, (i + 1) % 2])))      # both classes present
+    model = HG.Ganomaly(_args(tmp_path, "ganomaly", B, T, S), {"test": batches}, opt=HG.make_opt(isize=S, ngf=ngf))
+    model.netg.load_state_dict(og.state_dict())
+    F.invalidate_weight_cache()
+    ref = ganomaly_test(og, batches, OG.fold_frames)
+    perf = model.test()
+    torch.cuda.synchronize()
+    assert relerr(model.an_scores, torch.from_numpy(ref["an_scores"])) < 1e-3
+    assert np.array_equal(model.gt_labels.cpu().numpy(), ref["gt_labels"])
+    assert abs(perf["AUC"] - ref["AUC"]) < 1e-6
+    # BatchNorm ran in train mode: the running statistics moved exactly as the oracle's did
+    for (n, b), (_, br) in zip(model.netg.named_buffers(), og.named_buffers()):
+        assert relerr(b.float(), br.float()) < 1e-4, n
+    F.set_compute_dtype(torch.bfloat16)
+
+
 def test_train_loop_runs_the_sweep(dev, tmp_path):
     """GANBaseModel.train() (reference lib/train_gan.py:72-80): every `freq` steps the model's test() sweep and the summary
     update run inside the loop; scores land in score_dict and the scalar log."""

@@ -283,6 +283,34 @@ class Ganomaly(GANBaseModel):
         if join:
             self.reducer_d.finish()
 
+    def test(self):
+        """Evaluation sweep of reference models/ganomaly.py:332-406 over ``self.dataloader['test']``: per frame the anomaly
+        score mean((latent_i - latent_o)^2) over the nz latent channels, min-max scaled over the whole test set, ROC AUC
+        against the labels (every frame of a clip carries the clip's label ``lb``).  As in the reference the nets are NOT
+        switched to eval mode (there is no ``.eval()`` in that file): under torch.no_grad() BatchNorm normalises with each
+        test batch's statistics and keeps updating the running ones.  Returns the reference's performance dict."""
+        import time
+        from collections import OrderedDict
+        from ..lib.evaluate import evaluate
+        scores, labels, times = [], [], []
+        with torch.no_grad():
+            for data in self.dataloader['test']:
+                t0 = time.time()
+                input, real, gt, lb = (d.to(self.device, non_blocking=True) for d in data)
+                x = fold_frames(F.to_cl(input))
+                self.fake, latent_i, latent_o = self.netg(x)
+                li, lo = latent_i.to_torch().float(), latent_o.to_torch().float()
+                err = torch.mean(torch.pow(li - lo, 2), dim=1)
+                scores.append(err.reshape(err.size(0)))
+                labels.append(lb.reshape(-1).repeat_interleave(err.size(0) // lb.numel()))
+                times.append(time.time() - t0)
+            an = torch.cat(scores)
+            self.gt_labels = torch.cat(labels).long()
+            self.an_scores = (an - torch.min(an)) / (torch.max(an) - torch.min(an))
+        auc = evaluate(self.gt_labels.cpu().numpy(), self.an_scores.cpu().numpy(), metric='roc')
+        import numpy as np
+        return OrderedDict([('Avg Run Time (ms/batch)', float(np.mean(np.array(times)[:100]) * 1000)), ('AUC', auc)])
+
     def reinit_d(self):
         """Reference :496-500: re-apply the initialiser to netD.  Replicas must stay identical, so rank 0's new
         weights are broadcast."""
