@@ -17,7 +17,11 @@ from vfd_gan_amd.lib.data import synthetic_batch  # noqa: E402
 
 mode, out = sys.argv[1], sys.argv[2]
 which = sys.argv[3] if len(sys.argv) > 3 else "ganomaly"
-rank, world = vdist.init_from_env(backend="gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+if os.environ.get("VFD_DIST_SINGLE") == "1":
+    rank, world = vdist.init_from_env(backend="nccl")       # one rank, RCCL: every collective issued for real (identity)
+    assert vdist.collectives_on() and torch.distributed.get_backend() == "nccl"
+else:
+    rank, world = vdist.init_from_env(backend="gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
 torch.cuda.set_device(0)
 F.set_compute_dtype(torch.float32)
 torch.manual_seed(3)
@@ -69,6 +73,6 @@ if rank == 0:
     sd = {k: v.detach().cpu().double().sum().item() for k, v in model.netg.state_dict().items() if v.dtype.is_floating_point}
     sd.update({"D." + k: v.detach().cpu().double().sum().item() for k, v in model.netd.state_dict().items() if v.dtype.is_floating_point})
     json.dump({"errors": model.errors(), "sums": sd, "world": world}, open(out, "w"))
-if world > 1:
-    torch.distributed.barrier()
+if vdist.collectives_on():
+    vdist.barrier()
     torch.distributed.destroy_process_group()

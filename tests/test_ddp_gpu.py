@@ -12,14 +12,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(mode, world, tmp_path, which="ganomaly"):
-    out = str(tmp_path / ("%s_%s_%d.json" % (which, mode, world)))
+def _run(mode, world, tmp_path, which="ganomaly", rccl_single=False):
+    out = str(tmp_path / ("%s_%s_%d%s.json" % (which, mode, world, "_rccl" if rccl_single else "")))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if rccl_single:
+            env.update(VFD_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), mode, out, which], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
@@ -41,3 +43,18 @@ def test_two_ranks_match_single_process(which, mode, dev, tmp_path):
         assert abs(two["errors"][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, two["errors"][k], v)
     for k, v in one["sums"].items():
         assert abs(two["sums"][k] - v) <= 1e-4 * max(abs(v), 1.0), (k, two["sums"][k], v)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("which", ["ganomaly", "anogan", "mygan"])
+def test_single_rank_rccl_matches_plain(which, mode, dev, tmp_path):
+    """The RCCL calls themselves on the one GPU this box has: a ONE-rank process group over backend "nccl"
+    (VFD_DIST_SINGLE=1) with every broadcast, bucket all-reduce (asynchronous, from autograd hooks in eager mode, between the
+    replayed phase graphs in graph mode, next to the filter-gradient side stream) and barrier issued for real; an
+    all-reduce over one rank is the identity, so the step must equal the plain single-process run."""
+    plain = _run(mode, 1, tmp_path, which)
+    rccl = _run(mode, 1, tmp_path, which, rccl_single=True)
+    for k, v in plain["errors"].items():
+        assert abs(rccl["errors"][k] - v) <= 2e-5 * max(abs(v), 1e-3), (k, rccl["errors"][k], v)
+    for k, v in plain["sums"].items():
+        assert abs(rccl["sums"][k] - v) <= 1e-4 * max(abs(v), 1.0), (k, rccl["sums"][k], v)

@@ -28,12 +28,27 @@ def world_size():
     return tdist.get_world_size() if is_initialized() else 1
 
 
+def _single_forced():
+    # VFD_DIST_SINGLE=1: a ONE-process group is created anyway and every collective of the data-parallel path is issued
+    # (all-reduce of one rank = identity).  This is how the RCCL calls themselves — communicator set-up, asynchronous
+    # handles from autograd hooks, wait() stream semantics next to the side stream and between replayed graphs — are
+    # exercised on a one-GPU box (tests/test_ddp_gpu.py::test_single_rank_rccl_*).
+    return bool(int(os.environ.get("VFD_DIST_SINGLE", "0") or 0))
+
+
+def collectives_on():
+    """True when the data-parallel machinery (broadcasts, gradient reductions, phase graphs) is active."""
+    return world_size() > 1 or (is_initialized() and _single_forced())
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun); no-op for a single process.
     backend defaults to "nccl" (= RCCL on ROCm) when a GPU is present, else "gloo"."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or is_initialized():
+    if is_initialized() or (ws <= 1 and not _single_forced()):
         return rank(), world_size()
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     use_gpu = torch.cuda.is_available()
@@ -47,7 +62,7 @@ def init_from_env(backend=None):
 
 def barrier():
     """Process-group barrier bound to this rank's device (RCCL wants the device named; gloo does not take one)."""
-    if world_size() > 1:
+    if collectives_on():
         if tdist.get_backend() == "nccl" and torch.cuda.is_available():
             tdist.barrier(device_ids=[torch.cuda.current_device()])
         else:
@@ -56,7 +71,7 @@ def barrier():
 
 def broadcast_module(module, src=0):
     """Make every replica start from rank `src`'s parameters and buffers (DataParallel replicates each forward)."""
-    if world_size() == 1:
+    if not collectives_on():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -98,6 +113,7 @@ class GradReducer:
         self.params = list(params)
         self.arena = grad_arena
         self.world = world_size()
+        self.collective = collectives_on()
         self.buckets, self.owner = make_buckets(slices, int(bucket_mb * (1 << 20) / 4))
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
@@ -137,7 +153,7 @@ class GradReducer:
         if self.launched[b]:
             return
         self.launched[b] = True
-        if self.world > 1:
+        if self.collective:
             lo, hi, _ = self.buckets[b]
             self.handles.append(tdist.all_reduce(self.arena[lo:hi], op=tdist.ReduceOp.SUM, async_op=True))
 

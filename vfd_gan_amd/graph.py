@@ -51,7 +51,7 @@ class GraphedStep:
                 self._eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        if vdist.world_size() > 1:
+        if vdist.collectives_on():
             if not hasattr(m, "step_program"):
                 raise NotImplementedError("%s has no step_program() for data-parallel graph capture" % type(m).__name__)
             program = m.step_program()
@@ -71,7 +71,11 @@ class GraphedStep:
             for kind, obj in program:
                 if kind == "graph":
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
+                    # capture_error_mode "thread_local": in the default "global" mode EVERY thread's capture-unsafe call
+                    # fails while the capture is open, and RCCL's watchdog thread polls the events of earlier collectives
+                    # (hipEventQuery) whenever it likes — found by the single-rank RCCL test (mygan, graph mode: "operation
+                    # not permitted when stream is capturing" raised inside ProcessGroupNCCL's watchdog, process aborted)
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                         obj()
                         F.join_side_stream()      # a side stream forked inside the capture must rejoin before it ends
                     pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool
