@@ -339,7 +339,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model, a.isize, a.nfr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if vdist.is_initialized():      # world > 1, or the single-rank RCCL rehearsal (VFD_DIST_SINGLE=1)
         vdist.barrier()
         tdist.destroy_process_group()
 
