@@ -230,6 +230,22 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
                         float slope, float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc, void* ws,
                         void* stream);
 
+/* BatchNorm -> activation -> AvgPool3d (kernel = stride = (pd,ph,pw), each 1 or 2) in one forward pass and two backward
+ * launches, for an activation whose only consumer is the pool (models/anogan.py:84-105: NetD's three blocks;
+ * models/mygannet.py:132-133,174-175: SDisc / TDisc): x is [N][D][H][W][Cp], y the POOLED tensor
+ * [N][D/pd][H/ph][W/pw][Cp]; the full-resolution activation is never written, and the backward takes the POOLED gradient
+ * `gpool` (dy = gpool / (pd*ph*pw) at each input voxel of the window) and writes dx at full resolution.  Statistics, sums,
+ * dgamma / dbeta, colsum_acc as in vfd_bn_act_forward_sums / vfd_bn_act_backward_sums (over the INPUT voxels).      */
+int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw,
+                                 int C, const float* sums,
+                                 float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, const float* gamma,
+                                 const float* beta, int act, float slope, void* stream);
+int vfd_bn_act_pool_backward_sums(int dtype, const void* x, const void* gpool, void* dx, int N, int D, int H, int W,
+                                  int pd, int ph, int pw, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                  int act, float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
+                                  float* dbeta_acc, float* colsum_acc, void* stream);
+
 /* The apply pass alone, for a gradient that arrives as g = dy*act'(.) with sums[VFD_STATS_REPLICAS][2][Cp] = the
  * per-channel sums of g and g*xhat (vfd_conv_forward_bn_backward): dgamma/dbeta are published by the first row of
  * workgroups (OVERWRITTEN; *_acc ACCUMULATED into), dx as above.  One launch instead of three.

@@ -519,3 +519,84 @@ def test_pack_filters_batched_equals_single(dev):
 def _lib_check(rc):
     from vfd_gan_amd._lib import check
     check(rc, "pack_filter")
+
+
+@pytest.mark.parametrize("pools", [((2, 2, 2), (2, 2, 2)), ((1, 2, 2), (2, 1, 1))], ids=["pool222", "pool122_211"])
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_batchnorm_activation_avgpool_fused(dt, pools, dev):
+    """Conv3d -> BatchNorm3d -> LeakyReLU -> AvgPool3d(2) -> Conv3d (anogan NetD's block, models/anogan.py:84-105): the
+    normalise + activate + pool pass writes only the pooled tensor and BatchNorm's backward takes the pooled gradient
+    (vfd_bn_act_pool_forward_sums / vfd_bn_act_pool_backward_sums), against torch and against the unfused path; f32 with the
+    epilogue statistics switched on pins the arithmetic, bf16 is the production path.  Pools (2,2,2) (anogan) and (1,2,2) /
+    (2,1,1) (mygan's SDisc / TDisc).  Conv biases included (their gradient
+    comes out of the fused apply pass)."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import _lib, functional as F
+    torch.manual_seed(21)
+    spec = lambda M: [M.Conv3d(6, 40, 3, 1, 1), M.BatchNorm3d(40), M.LeakyReLU(0.2), M.AvgPool3d(pools[0]),      # noqa: E731
+                      M.Conv3d(40, 72, 3, 1, 1), M.BatchNorm3d(72), M.LeakyReLU(64.0), M.AvgPool3d(pools[1]), M.Conv3d(72, 8, 1, 1, 0)]
+    ref = torch.nn.Sequential(*spec(torch.nn))
+    with torch.no_grad():
+        for m in ref:
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.3)
+        if dt == torch.bfloat16:
+            for prm in ref.parameters():
+                prm.copy_(prm.bfloat16().float())
+    x = _rand((2, 6, 4, 12, 8), 61)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    gy = _rand(tuple(yr.shape), 62)
+    yr.backward(gy)
+    lib = _lib.load()
+    vnn.set_epilogue_stats("on")
+    results = {}
+    try:
+        for mode in ("fused", "unfused"):
+            mine = vnn.Sequential(*spec(vnn))
+            mine.load_state_dict(state0)
+            mine.to(dev)
+            calls = {}
+            origs = {nm: _count_calls(lib, nm, calls) for nm in ("vfd_bn_act_pool_forward_sums", "vfd_bn_act_pool_backward_sums", "vfd_avgpool_forward")}
+            old = vnn._NO_HANDOVER
+            vnn._NO_HANDOVER = mode == "unfused"
+            try:
+                xd = x.to(dev).requires_grad_()
+                y = mine(F.to_cl(xd, dt)).to_torch()
+                y.backward(gy.to(dev))
+                torch.cuda.synchronize()
+            finally:
+                vnn._NO_HANDOVER = old
+                for nm, o in origs.items():
+                    setattr(lib, nm, o)
+            if mode == "fused":
+                assert calls.get("vfd_bn_act_pool_forward_sums", 0) == 2 and calls.get("vfd_bn_act_pool_backward_sums", 0) == 2, calls
+                assert calls.get("vfd_avgpool_forward", 0) == 0
+            else:
+                assert calls.get("vfd_bn_act_pool_forward_sums", 0) == 0 and calls.get("vfd_avgpool_forward", 0) == 2
+            results[mode] = (y, xd.grad, {n: p.grad.clone() for n, p in mine.named_parameters()}, {n: b.clone() for n, b in mine.named_buffers()})
+    finally:
+        vnn.set_epilogue_stats("auto")
+    tol = TOL[dt] * (10 if dt == torch.float32 else 2)
+    for mode, (y, gx, grads, bufs) in results.items():
+        assert relerr(y, yr) < tol, (mode, relerr(y, yr))
+        assert relerr(gx, xr.grad) < (tol if dt == torch.float32 else 0.1), (mode, relerr(gx, xr.grad))
+        for n, pr in ref.named_parameters():
+            if n in ("0.bias", "4.bias"):       # bias in front of a BatchNorm: zero up to rounding, in torch as here
+                assert float(grads[n].abs().max()) < 2e-2 * float(grads[n.replace("bias", "weight")].abs().max()), (mode, n)
+                continue
+            e = relrms(grads[n], pr.grad)
+            assert e < (tol if dt == torch.float32 else 0.08), (mode, n, e)
+        for n, br in ref.named_buffers():
+            assert relerr(bufs[n].float(), br.float()) < 2e-3, (mode, n)
+    assert relerr(results["fused"][0], results["unfused"][0]) < (1e-5 if dt == torch.float32 else 1e-2)
+    # (bf16, max-norm: single elements whose pre-activation rounds to the other side of 0 in one of the two paths change by
+    # the derivative jump, 63x for LeakyReLU(64): the rms is the meaningful figure)
+    if dt == torch.float32:
+        assert relerr(results["fused"][1], results["unfused"][1]) < 1e-4
+    else:
+        assert relrms(results["fused"][1], results["unfused"][1]) < 1e-1      # measured 6.8e-2 (the slope-64 layer)

@@ -247,11 +247,34 @@ struct BnSumsArg {
   long long* nbt;
 };
 
-template <typename T, int ACT, bool SUMS>
+// POOL variants (BatchNorm -> activation -> AvgPool3d with kernel = stride in {1,2}^3 and no other consumer of the
+// activation: anogan's NetD, models/anogan.py:84-105; mygan's SDisc / TDisc, models/mygannet.py:132-133,174-175): the kernels walk the POOLED rows; a thread reads the 8 input rows of its pooled voxel.  The
+// forward writes only the pooled tensor (the full-resolution activation is never needed again: BatchNorm's backward works
+// from x), the backward passes take the POOLED gradient and form dy = gp / nq on the fly: per layer and direction the
+// full-resolution activation / gradient tensor is neither written nor re-read (2 + 3 tensor passes fewer).
+struct PoolArg {
+  int D, H, W;      // INPUT extents, multiples of the pool extents
+  int pd, ph, pw;   // pool kernel = stride, each 1 or 2 (AvgPool3d(2), (1,2,2), (2,1,1)): nq = pd*ph*pw inputs per pooled voxel
+};
+__device__ __forceinline__ long long pool_base_row(long long ro, const PoolArg& pa) {
+  const int Wo = pa.W / pa.pw, Ho = pa.H / pa.ph, Do = pa.D / pa.pd;
+  long long q = ro;
+  const int wo = (int)(q % Wo); q /= Wo;
+  const int ho = (int)(q % Ho); q /= Ho;
+  const int dq = (int)(q % Do); q /= Do;      // q = n
+  return ((q * pa.D + pa.pd * dq) * pa.H + pa.ph * ho) * pa.W + pa.pw * wo;
+}
+// row offset of input q (< nq) of a pooled voxel: q enumerates (i < pd, j < ph, k < pw), k fastest
+__device__ __forceinline__ long long pool_off(int q, const PoolArg& pa) {
+  const int k = q % pa.pw, j = (q / pa.pw) % pa.ph, i = q / (pa.pw * pa.ph);
+  return ((long long)i * pa.H + j) * pa.W + k;
+}
+
+template <typename T, int ACT, bool SUMS, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int TX,
                                                          long long rpb, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float slope, BnSumsArg sa) {
+                                                         const float* __restrict__ beta, float slope, BnSumsArg sa, PoolArg pa = PoolArg()) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   if (g >= GR) return;
   float sc[8], sf[8];
   if constexpr (SUMS) {
-    const double n = (double)rows, inv_n = 1.0 / n;
+    const double n = (double)rows * (POOL ? (double)(pa.pd * pa.ph * pa.pw) : 1.0), inv_n = 1.0 / n;      // statistics are over the INPUT rows
     const bool publish = blockIdx.y == 0 && ty == 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -298,6 +321,27 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   const long long rbeg = (long long)blockIdx.y * rpb;
   long long rend = rbeg + rpb;
   if (rend > rows) rend = rows;
+  if constexpr (POOL) {
+    for (long long r = rbeg + ty; r < rend; r += TY) {
+      const long long b0 = pool_base_row(r, pa);
+      const int nq = pa.pd * pa.ph * pa.pw;
+      const float inv_q = 1.f / (float)nq;
+      float v[8][8], o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < nq) a += act_c<ACT>(v[q][k] * sc[k] + sf[k], slope);
+        o[k] = (g * 8 + k < C) ? a * inv_q : 0.f;
+      }
+      store8(y + r * Cp + g * 8, o);
+    }
+    return;
+  }
   for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
     float v[ROWS_U][8];
 #pragma unroll
@@ -319,12 +363,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 // SUMS: the workgroup's partial sums are added into a replica row of a zeroed [VFD_STATS_REPLICAS][2][Cp] buffer (float
 // atomics, one per channel and workgroup) instead of a slot of the partials workspace: no finalize launch, the apply
 // kernel folds the replicas itself.
-template <typename T, int ACT, bool SUMS>
+template <typename T, int ACT, bool SUMS, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                  float* __restrict__ part, long long rows, int C, int TX,
                                                                  long long rpb, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta, float slope) {
+                                                                 const float* __restrict__ beta, float slope, PoolArg pa = PoolArg()) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
@@ -343,6 +387,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
     const long long rbeg = (long long)blockIdx.y * rpb;
     long long rend = rbeg + rpb;
     if (rend > rows) rend = rows;
+    if constexpr (POOL) {
+      for (long long r = rbeg + ty; r < rend; r += TY) {      // dy = the pooled gradient / 8 at each of the 8 input rows
+        const long long b0 = pool_base_row(r, pa);
+        const int nq = pa.pd * pa.ph * pa.pw;
+        const float inv_q = 1.f / (float)nq;
+        float v[8][8], gp[8];
+        load8(dy + r * Cp + g * 8, gp);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (q < nq) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float xh = (v[q][k] - mu[k]) * rs[k];
+              const float gz = gp[k] * inv_q * act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
+              sg[k] += gz; sgx[k] += gz * xh;
+            }
+          }
+        }
+      }
+    } else
     for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
       float v[ROWS_U][8], d[ROWS_U][8];
 #pragma unroll
@@ -467,14 +534,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
 // launch are gone; the row-0 workgroups publish dgamma / dbeta.
 // ACT < 0: gz IS g (conv hand-over); ACT >= 0: gz is dy and g = dy * act'(gamma * xhat + beta) is formed here, as in
 // bn_act_bwd_apply_kernel (the sums then come from bn_act_bwd_partial_kernel<.., SUMS>).
-template <typename T, int ACT>
+template <typename T, int ACT, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restrict__ x, const T* __restrict__ gz, T* __restrict__ dx,
                                                                 long long rows, int C, int TX, long long rpb,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float slope, const float* __restrict__ sums,
                                                                 float* dgamma, float* dbeta, float* dgamma_acc, float* dbeta_acc,
-                                                                float* colsum_acc) {
+                                                                float* colsum_acc, PoolArg pa = PoolArg()) {
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
@@ -491,7 +558,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
   float A[8], B[8], D[8], E[8], Fz[8], cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
-  const float inv = 1.f / (float)rows;
+  const float inv = 1.f / ((float)rows * (POOL ? (float)(pa.pd * pa.ph * pa.pw) : 1.f));      // means are over the INPUT rows
   {
     const bool publish = blockIdx.y == 0 && ty == 0;
 #pragma unroll
@@ -518,6 +585,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
   const long long rbeg = (long long)blockIdx.y * rpb;
   long long rend = rbeg + rpb;
   if (rend > rows) rend = rows;
+  if constexpr (POOL) {
+    for (long long r = rbeg + ty; r < rend; r += TY) {
+      const long long b0 = pool_base_row(r, pa);
+      const int nq = pa.pd * pa.ph * pa.pw;
+      const float inv_q = 1.f / (float)nq;
+      float v[8][8], gp[8];
+      load8(gz + r * Cp + g * 8, gp);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (q < nq) {
+          float o[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            float gzv = gp[k] * inv_q;
+            if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[q][k] * E[k] + Fz[k], slope);
+            o[k] = gzv * A[k] + (v[q][k] * B[k] + D[k]);
+            cs[k] += o[k];
+          }
+          store8(dx + (b0 + pool_off(q, pa)) * Cp + g * 8, o);
+        }
+      }
+    }
+  } else
   for (long long r = rbeg + ty; r < rend; r += (long long)ROWS_U * TY) {
     float v[ROWS_U][8], d[ROWS_U][8];
 #pragma unroll
@@ -671,6 +764,55 @@ extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_
   BN_ACT_DISPATCH(BN_FWD);
 #undef BN_FWD
   VFD_CHECK_LAUNCH("bn_act_forward_sums");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw, int C, const float* sums,
+                                            float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                                            float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
+                                            int act, float slope, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_pool_forward_sums: bad dtype");
+  VFD_REQUIRE(x && y && sums && mean && rstd && N > 0 && C > 0, "bn_act_pool_forward_sums: bad arguments");
+  VFD_REQUIRE((pd == 1 || pd == 2) && (ph == 1 || ph == 2) && (pw == 1 || pw == 2), "bn_act_pool_forward_sums: pool extents must be 1 or 2");
+  VFD_REQUIRE(D > 0 && H > 0 && W > 0 && D % pd == 0 && H % ph == 0 && W % pw == 0, "bn_act_pool_forward_sums: %dx%dx%d is not a multiple of the pool %dx%dx%d", D, H, W, pd, ph, pw);
+  const long long orows = (long long)N * (D / pd) * (H / ph) * (W / pw);
+  const Tiling t = make_stream_tiling(orows, C);
+  dim3 grid(t.gx, t.gy);
+  BnSumsArg sa;
+  sa.sums = sums; sa.eps = eps; sa.momentum = momentum; sa.mean_o = mean; sa.rstd_o = rstd;
+  sa.rmean = running_mean; sa.rvar = running_var; sa.nbt = reinterpret_cast<long long*>(num_batches_tracked);
+  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw;
+#define BN_FWDP(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_, true, true>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, orows, C, t.TX, t.rows_per_block, nullptr, nullptr, gamma, beta, slope, sa, pa)
+  BN_ACT_DISPATCH(BN_FWDP);
+#undef BN_FWDP
+  VFD_CHECK_LAUNCH("bn_act_pool_forward_sums");
+  return VFD_OK;
+}
+
+extern "C" int vfd_bn_act_pool_backward_sums(int dtype, const void* x, const void* gpool, void* dx, int N, int D, int H, int W, int pd, int ph, int pw, int C,
+                                             const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                             float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
+                                             float* dbeta_acc, float* colsum_acc, void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_pool_backward_sums: bad dtype");
+  VFD_REQUIRE(x && gpool && dx && mean && rstd && sums && dgamma && dbeta && N > 0 && C > 0, "bn_act_pool_backward_sums: bad arguments");
+  VFD_REQUIRE((pd == 1 || pd == 2) && (ph == 1 || ph == 2) && (pw == 1 || pw == 2), "bn_act_pool_backward_sums: pool extents must be 1 or 2");
+  VFD_REQUIRE(D > 0 && H > 0 && W > 0 && D % pd == 0 && H % ph == 0 && W % pw == 0, "bn_act_pool_backward_sums: extents are not a multiple of the pool");
+  const long long orows = (long long)N * (D / pd) * (H / ph) * (W / pw);
+  static const int pnb = getenv("VFD_BN_PART_BLOCKS") ? atoi(getenv("VFD_BN_PART_BLOCKS")) : 512;
+  const Tiling t = make_tiling(orows, C, pnb < BN_MAX_BLOCKS ? pnb : BN_MAX_BLOCKS, 1);
+  dim3 grid(t.gx, t.gy);
+  hipStream_t st = as_stream(stream);
+  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw;
+#define BN_BWD_PP(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_, true, true>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)gpool, sums, orows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope, pa)
+  BN_ACT_DISPATCH(BN_BWD_PP);
+#undef BN_BWD_PP
+  VFD_CHECK_LAUNCH("bn_act_pool_bwd_partial");
+  const Tiling ta = make_tiling(orows, C, 512, 1);
+  dim3 grid2(ta.gx, ta.gy);
+#define BN_BWD_AP(T_, ACT_) hipLaunchKernelGGL((bn_bwd_apply_sums_kernel<T_, ACT_, true>), grid2, dim3(256), 0, st, (const T_*)x, (const T_*)gpool, (T_*)dx, orows, C, ta.TX, ta.rows_per_block, mean, rstd, gamma, beta, slope, sums, dgamma, dbeta, dgamma_acc, dbeta_acc, colsum_acc, pa)
+  BN_ACT_DISPATCH(BN_BWD_AP);
+#undef BN_BWD_AP
+  VFD_CHECK_LAUNCH("bn_act_pool_bwd_apply");
   return VFD_OK;
 }
 

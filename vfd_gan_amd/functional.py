@@ -881,6 +881,73 @@ class _BnAct(torch.autograd.Function):
                 dbeta if (beta is not None and db_acc is None and not frozen) else None) + nret
 
 
+class _BnActPool(torch.autograd.Function):
+    """BatchNorm (statistics from the producing conv's epilogue sums) -> activation -> AvgPool3d(2), the activation having no
+    other consumer: vfd_bn_act_pool_forward_sums / vfd_bn_act_pool_backward_sums."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, bwd_sums, conv_bias,
+                bias_token, pool):
+        lib = load()
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        pd, ph, pw = pool
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(C, dtype=torch.float32, device=dev)
+        y = torch.empty((N, D // pd, H // ph, W // pw, Cp), dtype=x.dtype, device=dev)
+        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+        check(lib.vfd_bn_act_pool_forward_sums(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), N, D, H, W, pd, ph, pw, C, sums.data_ptr(), eps,
+                                               momentum, mean.data_ptr(), rstd.data_ptr(), ptr(running_mean), ptr(running_var),
+                                               ptr(nbt), ptr(g_), ptr(b_), act, slope, stream()), "bn_act_pool_forward_sums")
+        _LAST_BN_STATS[0] = (mean, rstd, N * D * H * W)
+        ctx.meta = (N, D, H, W, C, act, slope, pool)
+        ctx.bwd_sums = bwd_sums
+        ctx.cs_rep = None
+        if (bias_token is not None and conv_bias is not None and conv_bias.requires_grad and _direct_grad(conv_bias) is not None):
+            bias_token["taken"] = True
+            ctx.cs_rep = bias_token["rep"]
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gp):
+        lib = load()
+        N, D, H, W, C, act, slope, (pd, ph, pw) = ctx.meta
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        gp = gp.contiguous()
+        dev = x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
+        frozen = _frozen(gamma) or _frozen(beta)
+        dg_acc = _direct_grad(gamma) if (ctx.needs_input_grad[1] and not frozen) else None
+        db_acc = _direct_grad(beta) if (ctx.needs_input_grad[2] and not frozen) else None
+        check(lib.vfd_bn_act_pool_backward_sums(dtype_code(x.dtype), x.data_ptr(), gp.data_ptr(), dx.data_ptr(), N, D, H, W, pd, ph, pw, C,
+                                                mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope,
+                                                ctx.bwd_sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc),
+                                                ptr(ctx.cs_rep), stream()), "bn_act_pool_backward_sums")
+        return (dx, dgamma if (gamma is not None and dg_acc is None and not frozen) else None,
+                dbeta if (beta is not None and db_acc is None and not frozen) else None) + (None,) * 13
+
+
+def pool_fusable(kernel, stride, padding, in_dhw):
+    """AvgPool3d that _BnActPool can absorb: kernel == stride, every extent 1 or 2 (not all 1), no padding, input a multiple."""
+    k, s, p = _triple(kernel, 3, 1), _triple(stride if stride is not None else kernel, 3, 1), _triple(padding, 3, 0)
+    ok = k == s and p == (0, 0, 0) and all(v in (1, 2) for v in k) and k != (1, 1, 1) and all(d % v == 0 for d, v in zip(in_dhw, k))
+    return k if ok else None
+
+
+def bn_act_pool(x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, sums, num_batches_tracked, bwd_sums,
+                conv_bias=None, bias_token=None, pool=(2, 2, 2)):
+    """bn_act + AvgPool3d fused (see _BnActPool): x a 3-D channels-last block, `sums` the producing conv's epilogue statistics,
+    `bwd_sums` a zeroed sums buffer for the backward, `pool` = kernel = stride (pool_fusable)."""
+    y = _BnActPool.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act), float(slope),
+                         sums, num_batches_tracked, bwd_sums, conv_bias, bias_token, tuple(pool))
+    return ClTensor(y, x.C, x.nsp)
+
+
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,
            sums=None, num_batches_tracked=None, bwd_sums=None, conv_bias=None, bias_token=None):
     """Training-mode batch normalisation over all rows of `x` followed by `act`; updates the running statistics

@@ -24,18 +24,24 @@ from ..lib.utils import weights_init
 from .spatiotempconv import SpatioTemporalConv
 
 
-def _conv_bn_act(block, x, slope):
+def _conv_bn_act(block, x, slope, pool=None):
     """SpatioTemporalConv -> BatchNorm3d -> LeakyReLU(slope) with the BatchNorm statistics taken from the temporal
-    conv's epilogue (bf16) and normalise+activate in one pass."""
+    conv's epilogue (bf16) and normalise+activate in one pass.  `pool`: the AvgPool3d module the caller applies to the result
+    and to nothing else (the discriminators): absorbed into the BatchNorm pass where it can be (functional._BnActPool)."""
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
         buf = torch.zeros(3 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums | bias sums: one fill
         tbias = block.conv.temporal_conv.bias
         tok = {"taken": False, "rep": buf[2 * k:]} if tbias is not None else None
         x = block.conv(x, stats=buf[:k], bias_token=tok)
-        return block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:2 * k], conv_bias=tbias, bias_token=tok)
-    x = block.conv(x)
-    return block.bn(x, act=_lib.ACT_LRELU, slope=slope)
+        if pool is not None and not hnn._NO_HANDOVER and block.bn.momentum is not None:
+            pks = F.pool_fusable(pool.kernel_size, pool.stride, pool.padding, tuple(x.t.shape[1:4]))
+            if pks is not None:
+                return block.bn.forward_pooled(x, _lib.ACT_LRELU, slope, buf[:k], buf[k:2 * k], tbias, tok, pks)
+        x = block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:2 * k], conv_bias=tbias, bias_token=tok)
+        return pool(x) if pool is not None else x
+    x = block.bn(block.conv(x), act=_lib.ACT_LRELU, slope=slope)
+    return pool(x) if pool is not None else x
 
 
 class NetgConv(tnn.Module):
@@ -99,8 +105,8 @@ class NetdConv(tnn.Module):
         self.bn = hnn.BatchNorm3d(out_fi)
         self.lrelu = hnn.LeakyReLU()
 
-    def forward(self, x):
-        return _conv_bn_act(self, x, self.lrelu.negative_slope)
+    def forward(self, x, pool=None):
+        return _conv_bn_act(self, x, self.lrelu.negative_slope, pool)
 
 
 class SDisc(tnn.Module):
@@ -124,7 +130,7 @@ class SDisc(tnn.Module):
         if plain:
             x = F.to_cl(x)
         for conv in (self.dconv1, self.dconv2, self.dconv3, self.dconv4, self.dconv5, self.dconv6):
-            x = self.avgpool(conv(x))
+            x = conv(x, pool=self.avgpool)      # conv -> BatchNorm -> LeakyReLU -> AvgPool, the pool inside the BatchNorm pass
         features = x
         x = self.gpool(features)
         classifier = self.linear(x, act=_lib.ACT_SIGMOID)     # Linear over the flattened block + Sigmoid
@@ -151,7 +157,7 @@ class TDisc(tnn.Module):
         if plain:
             x = F.to_cl(x)
         for conv in (self.dconv1, self.dconv2, self.dconv3):
-            x = self.avgpool(conv(x))
+            x = conv(x, pool=self.avgpool)
         features = x
         x = self.gpool(features)
         classifier = self.linear(x, act=_lib.ACT_SIGMOID)

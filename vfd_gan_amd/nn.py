@@ -109,6 +109,17 @@ class _BatchNormMixin:
             self._batch_stats = F._LAST_BN_STATS[0]      # (mean, rstd, rows): see repeat_running_update
         return y
 
+    def forward_pooled(self, x, act, slope, sums, bwd_sums, conv_bias=None, bias_token=None, pool=(2, 2, 2)):
+        """Training-mode forward fused with the activation and the AvgPool3d (kernel = stride = `pool`) that follow."""
+        nbt = self.num_batches_tracked if self.track_running_stats else None
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        y = F.bn_act_pool(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums,
+                          conv_bias, bias_token, pool)
+        if getattr(self, "_keep_batch_stats", False):
+            self._batch_stats = F._LAST_BN_STATS[0]
+        return y
+
     def repeat_running_update(self):
         """Apply the running-statistics update of the last training-mode forward once more (a repeated forward on the same
         input and weights, without the forward)."""
@@ -227,12 +238,28 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
         pool_off += k
         return buf
 
+    def pool2_after(j, in_dhw):
+        """(index, kernel) of an AvgPool3d right after BatchNorm j and its activation that the BatchNorm pass can absorb."""
+        k = bn_span(j)
+        if k < n and isinstance(mods[k], AvgPool3d) and not _NO_HANDOVER:
+            pm = mods[k]
+            ks = F.pool_fusable(pm.kernel_size, pm.stride, pm.padding, in_dhw)
+            if ks is not None:
+                return k, ks
+        return -1, None
+
     def run_bn(j, x, sums, conv=None, tok=None):
         """BatchNorm at j with the activation that follows it; returns (x, next index, x has a hand-over token).  `conv`
         (with bias token `tok`): the conv that feeds it — its bias gradient is the column sum of this BatchNorm's dx."""
         bn = mods[j]
         nxt_i = bn_span(j)
         a = _act_of(mods[j + 1]) if nxt_i == j + 2 else None
+        pk, pks = pool2_after(j, tuple(x.t.shape[1:4])) if x.nsp == 3 else (-1, None)
+        if pk >= 0 and sums is not None and bn.training and pool is not None and bn.momentum is not None:
+            # BatchNorm -> activation -> AvgPool3d, nothing else reads the activation: one pass writes the pooled tensor
+            act, slope = (a[0], a[1]) if a is not None else (_lib.ACT_NONE, 0.0)
+            y = bn.forward_pooled(x, act, slope, sums, take(bn.num_features), conv.bias if tok is not None else None, tok, pks)
+            return y, pk + 1, False
         kw = {"act": a[0], "slope": a[1]} if a is not None else {}
         if bn.training and pool is not None:
             kw["bwd_sums"] = take(bn.num_features)      # backward: reduce with atomics + folding apply, or the conv hand-over
