@@ -235,16 +235,19 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
  * models/mygannet.py:132-133,174-175: SDisc / TDisc): x is [N][D][H][W][Cp], y the POOLED tensor
  * [N][D/pd][H/ph][W/pw][Cp]; the full-resolution activation is never written, and the backward takes the POOLED gradient
  * `gpool` (dy = gpool / (pd*ph*pw) at each input voxel of the window) and writes dx at full resolution.  Statistics, sums,
- * dgamma / dbeta, colsum_acc as in vfd_bn_act_forward_sums / vfd_bn_act_backward_sums (over the INPUT voxels).      */
+ * dgamma / dbeta, colsum_acc as in vfd_bn_act_forward_sums / vfd_bn_act_backward_sums (over the INPUT voxels).
+ * y_full / g_full (NULL or full-resolution tensors): the activation ALSO has a full-resolution consumer (a U-Net skip
+ * connection, models/mygannet.py:74-94): the forward writes it as well, and the backward adds the gradient that arrived
+ * for it: dy = g_full + gpool / (pd*ph*pw) — no pooling-backward pass, no gradient-sum pass.                        */
 int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw,
                                  int C, const float* sums,
                                  float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                  float* running_var, int64_t* num_batches_tracked, const float* gamma,
-                                 const float* beta, int act, float slope, void* stream);
+                                 const float* beta, int act, float slope, void* y_full, void* stream);
 int vfd_bn_act_pool_backward_sums(int dtype, const void* x, const void* gpool, void* dx, int N, int D, int H, int W,
                                   int pd, int ph, int pw, int C, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                   int act, float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
-                                  float* dbeta_acc, float* colsum_acc, void* stream);
+                                  float* dbeta_acc, float* colsum_acc, const void* g_full, void* stream);
 
 /* The apply pass alone, for a gradient that arrives as g = dy*act'(.) with sums[VFD_STATS_REPLICAS][2][Cp] = the
  * per-channel sums of g and g*xhat (vfd_conv_forward_bn_backward): dgamma/dbeta are published by the first row of

@@ -600,3 +600,61 @@ def test_batchnorm_activation_avgpool_fused(dt, pools, dev):
         assert relerr(results["fused"][1], results["unfused"][1]) < 1e-4
     else:
         assert relrms(results["fused"][1], results["unfused"][1]) < 1e-1      # measured 6.8e-2 (the slope-64 layer)
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_batchnorm_activation_avgpool_fused_with_skip(dt, dev):
+    """The U-Net encoder form (models/mygannet.py:74-94): the activation feeds the AvgPool AND a full-resolution consumer.  One
+    BatchNorm pass writes both tensors; its backward adds the two gradients that come back (no pooling-backward pass, no
+    gradient-sum pass).  Against torch, f32 (epilogue statistics on) tightly, bf16 in rms."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F
+    torch.manual_seed(31)
+    T = torch.nn
+    r_c1, r_bn, r_ca, r_cb = T.Conv3d(5, 24, 3, 1, 1), T.BatchNorm3d(24), T.Conv3d(24, 16, 3, 1, 1), T.Conv3d(24, 8, (1, 3, 3), 1, (0, 1, 1))
+    with torch.no_grad():
+        r_bn.weight.copy_(torch.rand(24) + 0.5)
+        r_bn.bias.copy_(torch.randn(24) * 0.2)
+        if dt == torch.bfloat16:
+            for m in (r_c1, r_bn, r_ca, r_cb):
+                for prm in m.parameters():
+                    prm.copy_(prm.bfloat16().float())
+    x = _rand((2, 5, 4, 8, 12), 71)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in (r_c1, r_bn, r_ca, r_cb)]
+    xr = x.clone().requires_grad_()
+    full_r = torch.nn.functional.leaky_relu(r_bn(r_c1(xr)), 0.2)
+    ya_r, yb_r = r_ca(torch.nn.functional.avg_pool3d(full_r, 2)), r_cb(full_r)
+    ga, gb = _rand(tuple(ya_r.shape), 72), _rand(tuple(yb_r.shape), 73)
+    ((ya_r * ga).sum() + (yb_r * gb).sum()).backward()
+    V = vnn
+    c1, bn, ca, cb = V.Conv3d(5, 24, 3, 1, 1), V.BatchNorm3d(24), V.Conv3d(24, 16, 3, 1, 1), V.Conv3d(24, 8, (1, 3, 3), 1, (0, 1, 1))
+    for m, st in zip((c1, bn, ca, cb), state):
+        m.load_state_dict(st)
+        m.to(dev)
+    xd = x.to(dev).requires_grad_()
+    k = F.stats_buffer_numel(24)
+    buf = torch.zeros(3 * k, dtype=torch.float32, device=dev)
+    tok = {"taken": False, "rep": buf[2 * k:]}
+    h = c1(F.to_cl(xd, dt), stats=buf[:k], bias_token=tok)
+    pooled, full = bn.forward_pooled(h, _lib_act_lrelu(), 0.2, buf[:k], buf[k:2 * k], c1.bias, tok, (2, 2, 2), True)
+    ya, yb = ca(pooled).to_torch(), cb(full).to_torch()
+    ((ya.float() * ga.to(dev)).sum() + (yb.float() * gb.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    tol = TOL[dt] * (10 if dt == torch.float32 else 2)
+    assert relerr(ya, ya_r) < tol and relerr(yb, yb_r) < tol
+    assert relerr(full.to_torch(), full_r) < tol
+    chk = relerr if dt == torch.float32 else relrms
+    assert chk(xd.grad, xr.grad) < (tol if dt == torch.float32 else 0.05), chk(xd.grad, xr.grad)
+    for mine, ref in ((c1, r_c1), (bn, r_bn), (ca, r_ca), (cb, r_cb)):
+        for (n, pm), pr in zip(mine.named_parameters(), ref.parameters()):
+            if mine is c1 and n == "bias":
+                continue      # zero up to rounding (feeds a BatchNorm)
+            assert chk(pm.grad, pr.grad) < (tol if dt == torch.float32 else 0.05), (type(mine).__name__, n, chk(pm.grad, pr.grad))
+    assert relerr(bn.running_var, r_bn.running_var) < 2e-3
+
+
+def _lib_act_lrelu():
+    from vfd_gan_amd import _lib
+    return _lib.ACT_LRELU

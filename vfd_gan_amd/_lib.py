@@ -72,9 +72,9 @@ SIGNATURES = {
     "vfd_bn_act_backward_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_pool_forward_sums": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
-                                             c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
+                                             c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp, c_vp]),
     "vfd_bn_act_pool_backward_sums": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int,
-                                              c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                              c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_bn_act_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vfd_act_forward": (c_int, [c_int, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_vp]),

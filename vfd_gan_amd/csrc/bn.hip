@@ -255,6 +255,8 @@ struct BnSumsArg {
 struct PoolArg {
   int D, H, W;      // INPUT extents, multiples of the pool extents
   int pd, ph, pw;   // pool kernel = stride, each 1 or 2 (AvgPool3d(2), (1,2,2), (2,1,1)): nq = pd*ph*pw inputs per pooled voxel
+  void* full;       // forward: also write the full-resolution activation here (it has a second consumer, e.g. a U-Net skip);
+                    // backward: the gradient that arrived for that full-resolution output, added to gp / nq.  Null: pool only
 };
 __device__ __forceinline__ long long pool_base_row(long long ro, const PoolArg& pa) {
   const int Wo = pa.W / pa.pw, Ho = pa.H / pa.ph, Do = pa.D / pa.pd;
@@ -331,13 +333,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
       for (int q = 0; q < 8; ++q)
         if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float a = 0.f;
+      for (int k = 0; k < 8; ++k) o[k] = 0.f;
+      T* yfull = reinterpret_cast<T*>(pa.full);
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (q < nq) a += act_c<ACT>(v[q][k] * sc[k] + sf[k], slope);
-        o[k] = (g * 8 + k < C) ? a * inv_q : 0.f;
+      for (int q = 0; q < 8; ++q) {
+        if (q < nq) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            v[q][k] = (g * 8 + k < C) ? act_c<ACT>(v[q][k] * sc[k] + sf[k], slope) : 0.f;
+            o[k] += v[q][k];
+          }
+          if (yfull != nullptr) store8(yfull + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] *= inv_q;
       store8(y + r * Cp + g * 8, o);
     }
     return;
@@ -394,16 +404,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_partial_kernel(const T* __rest
         const float inv_q = 1.f / (float)nq;
         float v[8][8], gp[8];
         load8(dy + r * Cp + g * 8, gp);
+        const T* gfull = reinterpret_cast<const T*>(pa.full);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (q < nq) {
+            float gf[8];
+            if (gfull != nullptr) load8(gfull + (b0 + pool_off(q, pa)) * Cp + g * 8, gf);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
               const float xh = (v[q][k] - mu[k]) * rs[k];
-              const float gz = gp[k] * inv_q * act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
+              const float dyv = gp[k] * inv_q + (gfull != nullptr ? gf[k] : 0.f);
+              const float gz = dyv * act_grad_in_c<ACT>(xh * ga[k] + be[k], slope);
               sg[k] += gz; sgx[k] += gz * xh;
             }
           }
@@ -592,16 +606,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
       const float inv_q = 1.f / (float)nq;
       float v[8][8], gp[8];
       load8(gz + r * Cp + g * 8, gp);
+      const T* gfull = reinterpret_cast<const T*>(pa.full);
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (q < nq) load8(x + (b0 + pool_off(q, pa)) * Cp + g * 8, v[q]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if (q < nq) {
-          float o[8];
+          float o[8], gf[8];
+          if (gfull != nullptr) load8(gfull + (b0 + pool_off(q, pa)) * Cp + g * 8, gf);
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            float gzv = gp[k] * inv_q;
+            float gzv = gp[k] * inv_q + (gfull != nullptr ? gf[k] : 0.f);
             if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[q][k] * E[k] + Fz[k], slope);
             o[k] = gzv * A[k] + (v[q][k] * B[k] + D[k]);
             cs[k] += o[k];
@@ -770,7 +786,7 @@ extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_
 extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw, int C, const float* sums,
                                             float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                             float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
-                                            int act, float slope, void* stream) {
+                                            int act, float slope, void* y_full, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_pool_forward_sums: bad dtype");
   VFD_REQUIRE(x && y && sums && mean && rstd && N > 0 && C > 0, "bn_act_pool_forward_sums: bad arguments");
   VFD_REQUIRE((pd == 1 || pd == 2) && (ph == 1 || ph == 2) && (pw == 1 || pw == 2), "bn_act_pool_forward_sums: pool extents must be 1 or 2");
@@ -781,7 +797,7 @@ extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, i
   BnSumsArg sa;
   sa.sums = sums; sa.eps = eps; sa.momentum = momentum; sa.mean_o = mean; sa.rstd_o = rstd;
   sa.rmean = running_mean; sa.rvar = running_var; sa.nbt = reinterpret_cast<long long*>(num_batches_tracked);
-  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw;
+  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw; pa.full = y_full;
 #define BN_FWDP(T_, ACT_) hipLaunchKernelGGL((bn_act_fwd_kernel<T_, ACT_, true, true>), grid, dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, orows, C, t.TX, t.rows_per_block, nullptr, nullptr, gamma, beta, slope, sa, pa)
   BN_ACT_DISPATCH(BN_FWDP);
 #undef BN_FWDP
@@ -792,7 +808,7 @@ extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, i
 extern "C" int vfd_bn_act_pool_backward_sums(int dtype, const void* x, const void* gpool, void* dx, int N, int D, int H, int W, int pd, int ph, int pw, int C,
                                              const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                              float slope, float* sums, float* dgamma, float* dbeta, float* dgamma_acc,
-                                             float* dbeta_acc, float* colsum_acc, void* stream) {
+                                             float* dbeta_acc, float* colsum_acc, const void* g_full, void* stream) {
   VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "bn_act_pool_backward_sums: bad dtype");
   VFD_REQUIRE(x && gpool && dx && mean && rstd && sums && dgamma && dbeta && N > 0 && C > 0, "bn_act_pool_backward_sums: bad arguments");
   VFD_REQUIRE((pd == 1 || pd == 2) && (ph == 1 || ph == 2) && (pw == 1 || pw == 2), "bn_act_pool_backward_sums: pool extents must be 1 or 2");
@@ -802,7 +818,7 @@ extern "C" int vfd_bn_act_pool_backward_sums(int dtype, const void* x, const voi
   const Tiling t = make_tiling(orows, C, pnb < BN_MAX_BLOCKS ? pnb : BN_MAX_BLOCKS, 1);
   dim3 grid(t.gx, t.gy);
   hipStream_t st = as_stream(stream);
-  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw;
+  PoolArg pa; pa.D = D; pa.H = H; pa.W = W; pa.pd = pd; pa.ph = ph; pa.pw = pw; pa.full = const_cast<void*>(g_full);
 #define BN_BWD_PP(T_, ACT_) hipLaunchKernelGGL((bn_act_bwd_partial_kernel<T_, ACT_, true, true>), grid, dim3(256), 0, st, (const T_*)x, (const T_*)gpool, sums, orows, C, t.TX, t.rows_per_block, mean, rstd, gamma, beta, slope, pa)
   BN_ACT_DISPATCH(BN_BWD_PP);
 #undef BN_BWD_PP

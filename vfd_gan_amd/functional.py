@@ -887,7 +887,7 @@ class _BnActPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, C, running_mean, running_var, eps, momentum, act, slope, sums, nbt, bwd_sums, conv_bias,
-                bias_token, pool):
+                bias_token, pool, keep_full):
         lib = load()
         x = x.contiguous()
         N, D, H, W, Cp = x.shape
@@ -896,26 +896,31 @@ class _BnActPool(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         rstd = torch.empty(C, dtype=torch.float32, device=dev)
         y = torch.empty((N, D // pd, H // ph, W // pw, Cp), dtype=x.dtype, device=dev)
+        yfull = torch.empty_like(x) if keep_full else None      # the activation's second, full-resolution consumer (U-Net skip)
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         check(lib.vfd_bn_act_pool_forward_sums(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), N, D, H, W, pd, ph, pw, C, sums.data_ptr(), eps,
                                                momentum, mean.data_ptr(), rstd.data_ptr(), ptr(running_mean), ptr(running_var),
-                                               ptr(nbt), ptr(g_), ptr(b_), act, slope, stream()), "bn_act_pool_forward_sums")
+                                               ptr(nbt), ptr(g_), ptr(b_), act, slope, ptr(yfull), stream()), "bn_act_pool_forward_sums")
         _LAST_BN_STATS[0] = (mean, rstd, N * D * H * W)
         ctx.meta = (N, D, H, W, C, act, slope, pool)
+        ctx.keep_full = keep_full
         ctx.bwd_sums = bwd_sums
         ctx.cs_rep = None
         if (bias_token is not None and conv_bias is not None and conv_bias.requires_grad and _direct_grad(conv_bias) is not None):
             bias_token["taken"] = True
             ctx.cs_rep = bias_token["rep"]
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        return y
+        return (y, yfull) if keep_full else y
 
     @staticmethod
-    def backward(ctx, gp):
+    def backward(ctx, gp, gfull=None):
         lib = load()
         N, D, H, W, C, act, slope, (pd, ph, pw) = ctx.meta
         x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if gp is None:          # only the full-resolution output was used
+            gp = torch.zeros((N, D // pd, H // ph, W // pw, x.shape[-1]), dtype=x.dtype, device=x.device)
         gp = gp.contiguous()
+        gfull = gfull.contiguous() if gfull is not None else None
         dev = x.device
         dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
@@ -927,9 +932,9 @@ class _BnActPool(torch.autograd.Function):
         check(lib.vfd_bn_act_pool_backward_sums(dtype_code(x.dtype), x.data_ptr(), gp.data_ptr(), dx.data_ptr(), N, D, H, W, pd, ph, pw, C,
                                                 mean.data_ptr(), rstd.data_ptr(), ptr(g_), ptr(b_), act, slope,
                                                 ctx.bwd_sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ptr(dg_acc), ptr(db_acc),
-                                                ptr(ctx.cs_rep), stream()), "bn_act_pool_backward_sums")
+                                                ptr(ctx.cs_rep), ptr(gfull), stream()), "bn_act_pool_backward_sums")
         return (dx, dgamma if (gamma is not None and dg_acc is None and not frozen) else None,
-                dbeta if (beta is not None and db_acc is None and not frozen) else None) + (None,) * 13
+                dbeta if (beta is not None and db_acc is None and not frozen) else None) + (None,) * 14
 
 
 def pool_fusable(kernel, stride, padding, in_dhw):
@@ -940,12 +945,15 @@ def pool_fusable(kernel, stride, padding, in_dhw):
 
 
 def bn_act_pool(x, gamma, beta, running_mean, running_var, eps, momentum, act, slope, sums, num_batches_tracked, bwd_sums,
-                conv_bias=None, bias_token=None, pool=(2, 2, 2)):
+                conv_bias=None, bias_token=None, pool=(2, 2, 2), keep_full=False):
     """bn_act + AvgPool3d fused (see _BnActPool): x a 3-D channels-last block, `sums` the producing conv's epilogue statistics,
-    `bwd_sums` a zeroed sums buffer for the backward, `pool` = kernel = stride (pool_fusable)."""
-    y = _BnActPool.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act), float(slope),
-                         sums, num_batches_tracked, bwd_sums, conv_bias, bias_token, tuple(pool))
-    return ClTensor(y, x.C, x.nsp)
+    `bwd_sums` a zeroed sums buffer for the backward, `pool` = kernel = stride (pool_fusable).  keep_full: the activation has a
+    full-resolution consumer too; returns (pooled, full) and the backward sums the two incoming gradients itself."""
+    out = _BnActPool.apply(x.t, gamma, beta, x.C, running_mean, running_var, float(eps), float(momentum), int(act), float(slope),
+                           sums, num_batches_tracked, bwd_sums, conv_bias, bias_token, tuple(pool), bool(keep_full))
+    if keep_full:
+        return ClTensor(out[0], x.C, x.nsp), ClTensor(out[1], x.C, x.nsp)
+    return ClTensor(out, x.C, x.nsp)
 
 
 def bn_act(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, act=_lib.ACT_NONE, slope=0.0,

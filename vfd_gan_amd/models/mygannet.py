@@ -24,10 +24,11 @@ from ..lib.utils import weights_init
 from .spatiotempconv import SpatioTemporalConv
 
 
-def _conv_bn_act(block, x, slope, pool=None):
+def _conv_bn_act(block, x, slope, pool=None, keep_full=False):
     """SpatioTemporalConv -> BatchNorm3d -> LeakyReLU(slope) with the BatchNorm statistics taken from the temporal
     conv's epilogue (bf16) and normalise+activate in one pass.  `pool`: the AvgPool3d module the caller applies to the result
-    and to nothing else (the discriminators): absorbed into the BatchNorm pass where it can be (functional._BnActPool)."""
+    (the discriminators: to nothing else; NetG's encoder, keep_full: the full-resolution result is a skip connection too and
+    (pooled, full) is returned): absorbed into the BatchNorm pass where it can be (functional._BnActPool)."""
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
         buf = torch.zeros(3 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums | bias sums: one fill
@@ -37,11 +38,13 @@ def _conv_bn_act(block, x, slope, pool=None):
         if pool is not None and not hnn._NO_HANDOVER and block.bn.momentum is not None:
             pks = F.pool_fusable(pool.kernel_size, pool.stride, pool.padding, tuple(x.t.shape[1:4]))
             if pks is not None:
-                return block.bn.forward_pooled(x, _lib.ACT_LRELU, slope, buf[:k], buf[k:2 * k], tbias, tok, pks)
+                return block.bn.forward_pooled(x, _lib.ACT_LRELU, slope, buf[:k], buf[k:2 * k], tbias, tok, pks, keep_full)
         x = block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:2 * k], conv_bias=tbias, bias_token=tok)
-        return pool(x) if pool is not None else x
-    x = block.bn(block.conv(x), act=_lib.ACT_LRELU, slope=slope)
-    return pool(x) if pool is not None else x
+    else:
+        x = block.bn(block.conv(x), act=_lib.ACT_LRELU, slope=slope)
+    if pool is None:
+        return x
+    return (pool(x), x) if keep_full else pool(x)
 
 
 class NetgConv(tnn.Module):
@@ -52,8 +55,9 @@ class NetgConv(tnn.Module):
         self.bn = hnn.BatchNorm3d(out_fi)
         self.lrelu = hnn.LeakyReLU(0.2, inplace=True)
 
-    def forward(self, x):
-        return _conv_bn_act(self, x, self.lrelu.negative_slope)
+    def forward(self, x, pool=None):
+        """pool: the encoder's AvgPool3d -> returns (pooled, full-resolution) from one BatchNorm pass."""
+        return _conv_bn_act(self, x, self.lrelu.negative_slope, pool, keep_full=pool is not None)
 
 
 class NetG(tnn.Module):
@@ -83,11 +87,13 @@ class NetG(tnn.Module):
         plain = not isinstance(x, ClTensor)
         if plain:
             x = F.to_cl(x)
-        dconv1 = self.dconv1(x)
-        dconv2 = self.dconv2(self.avgpool(dconv1))
-        dconv3 = self.dconv3(self.avgpool(dconv2))
-        dconv4 = self.dconv4(self.avgpool(dconv3))
-        latent_i = self.dconv5(self.avgpool(dconv4))
+        # each encoder level feeds its pooled form to the next level and its full-resolution form to the decoder (skip):
+        # both come out of the level's BatchNorm pass, and that pass's backward sums the two gradients that come back
+        p1, dconv1 = self.dconv1(x, pool=self.avgpool)
+        p2, dconv2 = self.dconv2(p1, pool=self.avgpool)
+        p3, dconv3 = self.dconv3(p2, pool=self.avgpool)
+        p4, dconv4 = self.dconv4(p3, pool=self.avgpool)
+        latent_i = self.dconv5(p4)
 
         x = self.upsamp(self.dropout(self.uconv5(latent_i)))
         x = self.upsamp(self.dropout(self.uconv4(F.cat_channels(x, dconv4))))

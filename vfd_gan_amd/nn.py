@@ -109,13 +109,13 @@ class _BatchNormMixin:
             self._batch_stats = F._LAST_BN_STATS[0]      # (mean, rstd, rows): see repeat_running_update
         return y
 
-    def forward_pooled(self, x, act, slope, sums, bwd_sums, conv_bias=None, bias_token=None, pool=(2, 2, 2)):
+    def forward_pooled(self, x, act, slope, sums, bwd_sums, conv_bias=None, bias_token=None, pool=(2, 2, 2), keep_full=False):
         """Training-mode forward fused with the activation and the AvgPool3d (kernel = stride = `pool`) that follow."""
         nbt = self.num_batches_tracked if self.track_running_stats else None
         rm = self.running_mean if self.track_running_stats else None
         rv = self.running_var if self.track_running_stats else None
         y = F.bn_act_pool(x, self.weight, self.bias, rm, rv, self.eps, self.momentum, act, slope, sums, nbt, bwd_sums,
-                          conv_bias, bias_token, pool)
+                          conv_bias, bias_token, pool, keep_full)
         if getattr(self, "_keep_batch_stats", False):
             self._batch_stats = F._LAST_BN_STATS[0]
         return y
