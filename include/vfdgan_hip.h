@@ -288,6 +288,13 @@ int vfd_avgpool_backward(int dtype, const void* dy, void* dx, int N, int D, int 
 int vfd_upsample2x_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
 int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C,
                             void* stream);
+/* torch.cat([Upsample(x), skip], dim=1) in one pass (U-Net decoder joint, models/mygannet.py:78-94): x [N][D][H][W][Ca]
+ * (Ca a multiple of 8), skip [N][2D][2H][2W][CPAD(Cb)], y [N][2D][2H][2W][Ca + CPAD(Cb)]; the up-sampled tensor is never
+ * materialised.  Backward: dx from the first Ca channels of dcat read in place, dskip = the remaining channels.     */
+int vfd_upsample2x_cat_forward(int dtype, const void* x, const void* skip, void* y, int N, int D, int H, int W, int Ca,
+                               int Cb, void* stream);
+int vfd_upsample2x_cat_backward(int dtype, const void* dcat, void* dx, void* dskip, int N, int D, int H, int W, int Ca,
+                                int Cb, void* stream);
 /* Evaluation sweep post-processing on float32 planes [planes][H][W] (a (N,1,T,H,W) mask, planes = N*T): optional
  * threshold (x > threshold ? 1 : 0, lib/utils.py:149-152) followed by the 5 x 5 morphological opening of
  * lib/utils.py:139-147 (cv2.morphologyEx(MORPH_OPEN, ones(5,5)) per frame; cv2's default border: outside pixels do not take

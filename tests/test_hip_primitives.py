@@ -658,3 +658,28 @@ def test_batchnorm_activation_avgpool_fused_with_skip(dt, dev):
 def _lib_act_lrelu():
     from vfd_gan_amd import _lib
     return _lib.ACT_LRELU
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
+def test_upsample_cat_fused(dt, dev):
+    """F.upsample_cat == cat([Upsample(scale 2, trilinear, align_corners=True)(x), skip], dim=1), forward and both gradients
+    (the decoder joint of models/mygannet.py:78-94 written in one pass); ragged skip channel count."""
+    from vfd_gan_amd import functional as F
+    x = _rand((2, 16, 2, 3, 5), 81)
+    skip = _rand((2, 13, 4, 6, 10), 82)
+    if dt == torch.bfloat16:
+        x, skip = x.bfloat16().float(), skip.bfloat16().float()
+    xr, sr = x.clone().requires_grad_(), skip.clone().requires_grad_()
+    yr = torch.cat([torch.nn.functional.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True), sr], dim=1)
+    gy = _rand(tuple(yr.shape), 83)
+    yr.backward(gy)
+    xd, sd = x.to(dev).requires_grad_(), skip.to(dev).requires_grad_()
+    yc = F.upsample_cat(F.to_cl(xd, dt), F.to_cl(sd, dt))
+    assert yc.C == 29 and float(yc.t[..., yc.C:].float().abs().sum()) == 0.0
+    y = yc.to_torch()
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    tol = TOL[dt]
+    assert relerr(y, yr) < tol
+    assert relerr(xd.grad, xr.grad) < tol * (1 if dt == torch.float32 else 2), relerr(xd.grad, xr.grad)
+    assert relerr(sd.grad, sr.grad) < tol

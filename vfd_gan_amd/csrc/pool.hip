@@ -161,8 +161,64 @@ __device__ __forceinline__ float up_weight(int o, int i, int I, int O) {
   return w;
 }
 
+// torch.cat([Upsample(x), skip], dim=1) in one pass (the U-Net decoder joint, models/mygannet.py:78-94): output granule g of
+// pixel o is the interpolation of x for g < Cap/8, else the skip tensor's granule g - Cap/8.  Reads the (small) x and the skip
+// once, writes the concatenation once; the up-sampled tensor itself never exists.  Cap = channels of x, a multiple of 8.
 template <typename T>
-__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int D, int H, int W, int Cp) {
+__global__ void upsample2x_cat_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y, int N, int D, int H,
+                                          int W, int Cap, int Cbp) {
+  const int GA = Cap >> 3, GR = (Cap + Cbp) >> 3, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)N * Do * Ho * Wo * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long q = i;
+    const int g = (int)(q % GR); q /= GR;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g >= GA) {
+      load8(skip + q * Cbp + (g - GA) * 8, s);      // q = output pixel index
+    } else {
+      const int ow = (int)(q % Wo); q /= Wo;
+      const int oh = (int)(q % Ho); q /= Ho;
+      const int od = (int)(q % Do); q /= Do;
+      const int n = (int)q;
+      int d0, d1, h0, h1, w0, w1;
+      float ld, lh, lw;
+      up_src(od, D, Do, d0, d1, ld);
+      up_src(oh, H, Ho, h0, h1, lh);
+      up_src(ow, W, Wo, w0, w1, lw);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float wgt = (a ? ld : 1.f - ld) * (b ? lh : 1.f - lh) * (c ? lw : 1.f - lw);
+            const size_t pix = ((size_t)(n * D + (a ? d1 : d0)) * H + (b ? h1 : h0)) * W + (c ? w1 : w0);
+            float v[8];
+            load8(x + pix * Cap + g * 8, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += wgt * v[k];
+          }
+    }
+    store8(y + i * 8, s);
+  }
+}
+
+// channels [c0, c0 + 8*ng) of a [rows][srcCp] block -> a dense [rows][8*ng] block (the skip half of a concatenation's gradient)
+template <typename T>
+__global__ void slice_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long long rows, int srcCp, int g0, int ng) {
+  const long long total = rows * ng;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / ng;
+    const int g = (int)(i - r * ng);
+    float v[8];
+    load8(src + r * srcCp + (g0 + g) * 8, v);
+    store8(dst + i * 8, v);
+  }
+}
+
+// dyCp: row length of dy (>= Cp: the gradient may be the leading channels of a wider, concatenated tensor)
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int D, int H, int W, int Cp, int dyCp) {
   const int GR = Cp >> 3, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
   const long long total = (long long)N * D * H * W * GR;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -185,7 +241,7 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
           if (ww == 0.f) continue;
           const size_t pix = ((size_t)(n * Do + od) * Ho + oh) * Wo + ow;
           float v[8];
-          load8(dy + pix * Cp + g * 8, v);
+          load8(dy + pix * dyCp + g * 8, v);
           const float wgt = wd * wh * ww;
 #pragma unroll
           for (int k = 0; k < 8; ++k) s[k] += wgt * v[k];
@@ -257,9 +313,46 @@ extern "C" int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int 
   const int Cp = cpad(C);
   const long long total = (long long)N * D * H * W * (Cp >> 3);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, Cp);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, Cp, Cp);
   else
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, N, D, H, W, Cp);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, N, D, H, W, Cp, Cp);
   VFD_CHECK_LAUNCH("upsample2x_backward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_upsample2x_cat_forward(int dtype, const void* x, const void* skip, void* y, int N, int D, int H, int W, int Ca, int Cb,
+                                          void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "upsample2x_cat_forward: bad dtype");
+  VFD_REQUIRE(x && skip && y && N > 0 && D > 0 && H > 0 && W > 0 && Ca > 0 && Cb > 0, "upsample2x_cat_forward: bad arguments");
+  VFD_REQUIRE(Ca % 8 == 0, "upsample2x_cat_forward: the up-sampled tensor's channel count (%d) must be a multiple of 8", Ca);
+  const int Cbp = cpad(Cb);
+  const long long total = (long long)N * D * H * W * 8 * ((Ca + Cbp) >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(upsample2x_cat_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (const bf16_t*)skip, (bf16_t*)y, N, D, H, W, Ca, Cbp);
+  else
+    hipLaunchKernelGGL(upsample2x_cat_fwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)x, (const float*)skip, (float*)y, N, D, H, W, Ca, Cbp);
+  VFD_CHECK_LAUNCH("upsample2x_cat_forward");
+  return VFD_OK;
+}
+
+// gradient of the above: dx = transpose of the interpolation applied to the first Ca channels of dcat (read in place), dskip =
+// channels [Ca, Ca + CPAD(Cb)) of dcat as a dense block
+extern "C" int vfd_upsample2x_cat_backward(int dtype, const void* dcat, void* dx, void* dskip, int N, int D, int H, int W, int Ca, int Cb,
+                                           void* stream) {
+  VFD_REQUIRE(dtype == VFD_F32 || dtype == VFD_BF16, "upsample2x_cat_backward: bad dtype");
+  VFD_REQUIRE(dcat && dx && dskip && N > 0 && D > 0 && H > 0 && W > 0 && Ca > 0 && Cb > 0 && Ca % 8 == 0, "upsample2x_cat_backward: bad arguments");
+  const int Cbp = cpad(Cb), Ccat = Ca + Cbp;
+  const long long total = (long long)N * D * H * W * (Ca >> 3);
+  const long long orows = (long long)N * D * H * W * 8;
+  const long long tot2 = orows * (Cbp >> 3);
+  hipStream_t st = as_stream(stream);
+  if (dtype == VFD_BF16) {
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const bf16_t*)dcat, (bf16_t*)dx, N, D, H, W, Ca, Ccat);
+    hipLaunchKernelGGL(slice_copy_kernel<bf16_t>, dim3(pl_blocks(tot2)), dim3(PL_THREADS), 0, st, (const bf16_t*)dcat, (bf16_t*)dskip, orows, Ccat, Ca >> 3, Cbp >> 3);
+  } else {
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const float*)dcat, (float*)dx, N, D, H, W, Ca, Ccat);
+    hipLaunchKernelGGL(slice_copy_kernel<float>, dim3(pl_blocks(tot2)), dim3(PL_THREADS), 0, st, (const float*)dcat, (float*)dskip, orows, Ccat, Ca >> 3, Cbp >> 3);
+  }
+  VFD_CHECK_LAUNCH("upsample2x_cat_backward");
   return VFD_OK;
 }

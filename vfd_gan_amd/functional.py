@@ -1076,6 +1076,41 @@ def upsample_trilinear2x(x):
     return ClTensor(_Upsample2x.apply(x.t, x.C), x.C, x.nsp)
 
 
+class _UpsampleCat(torch.autograd.Function):
+    """torch.cat([Upsample(scale 2, trilinear, align_corners)(x), skip], dim=1) without the up-sampled intermediate."""
+
+    @staticmethod
+    def forward(ctx, x, skip, Ca, Cb):
+        x, skip = x.contiguous(), skip.contiguous()
+        N, D, H, W, _ = x.shape
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, Ca + cpad(Cb)), dtype=x.dtype, device=x.device)
+        check(load().vfd_upsample2x_cat_forward(dtype_code(x.dtype), x.data_ptr(), skip.data_ptr(), y.data_ptr(), N, D, H, W, Ca, Cb,
+                                                stream()), "upsample2x_cat_forward")
+        ctx.meta = (N, D, H, W, Ca, Cb, tuple(x.shape), tuple(skip.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, D, H, W, Ca, Cb, sx, ss = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty(sx, dtype=g.dtype, device=g.device)
+        ds = torch.empty(ss, dtype=g.dtype, device=g.device)
+        check(load().vfd_upsample2x_cat_backward(dtype_code(g.dtype), g.data_ptr(), dx.data_ptr(), ds.data_ptr(), N, D, H, W, Ca, Cb,
+                                                 stream()), "upsample2x_cat_backward")
+        return dx, ds, None, None
+
+
+def upsample_cat(x, skip):
+    """cat_channels(upsample_trilinear2x(x), skip) in one pass (x's channel count a multiple of 8, else the two-pass form)."""
+    if x.nsp != 3 or skip.nsp != 3:
+        raise RuntimeError("upsample_cat expects (N,C,D,H,W) blocks")
+    if x.C % 8 != 0 or x.t.shape[-1] != x.C:
+        return cat_channels(upsample_trilinear2x(x), skip)
+    if tuple(skip.t.shape[:4]) != (x.t.shape[0], 2 * x.t.shape[1], 2 * x.t.shape[2], 2 * x.t.shape[3]):
+        raise RuntimeError("upsample_cat: skip %s is not twice x %s" % (skip.shape, x.shape))
+    return ClTensor(_UpsampleCat.apply(x.t, skip.t, x.C, skip.C), x.C + skip.C, 3)
+
+
 class _Concat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, Ca, Cb):

@@ -95,11 +95,14 @@ class NetG(tnn.Module):
         p4, dconv4 = self.dconv4(p3, pool=self.avgpool)
         latent_i = self.dconv5(p4)
 
-        x = self.upsamp(self.dropout(self.uconv5(latent_i)))
-        x = self.upsamp(self.dropout(self.uconv4(F.cat_channels(x, dconv4))))
-        x = self.upsamp(self.dropout(self.uconv3(F.cat_channels(x, dconv3))))
-        x = self.upsamp(self.dropout(self.uconv2(F.cat_channels(x, dconv2))))
-        x = self.uconv1(F.cat_channels(x, dconv1))
+        # decoder joints: cat([Upsample(x), skip]) written in one pass (F.upsample_cat; self.upsamp's configuration is the
+        # one that pass implements: scale 2, trilinear, align_corners=True, checked by hnn.Upsample at construction use)
+        self.upsamp.check()
+        x = self.dropout(self.uconv5(latent_i))
+        x = self.dropout(self.uconv4(F.upsample_cat(x, dconv4)))
+        x = self.dropout(self.uconv3(F.upsample_cat(x, dconv3)))
+        x = self.dropout(self.uconv2(F.upsample_cat(x, dconv2)))
+        x = self.uconv1(F.upsample_cat(x, dconv1))
         predict = self.conv_last(x, act=_lib.ACT_SIGMOID)      # conv_last + sigmoid in one kernel
         return predict.to_torch() if plain else predict
 

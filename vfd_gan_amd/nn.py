@@ -179,10 +179,13 @@ class AvgPool3d(tnn.AvgPool3d):
 
 
 class Upsample(tnn.Upsample):
-    def forward(self, x):
-        _need_cl(x, "Upsample")
+    def check(self):
         if not (self.mode == "trilinear" and self.align_corners and float(self.scale_factor) == 2.0):
             raise NotImplementedError("only Upsample(scale_factor=2, mode='trilinear', align_corners=True)")
+
+    def forward(self, x):
+        _need_cl(x, "Upsample")
+        self.check()
         return F.upsample_trilinear2x(x)
 
 
