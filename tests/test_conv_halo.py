@@ -153,6 +153,9 @@ WG_CASES = [
     # gathered operand with <= 32 channels: 64-byte halo rows, two depth taps per work item (anogan NetD 32 -> 64)
     ("c3d_k3_32to64", (2, 32, 6, 9, 20), 64, 3, 1, 1, 0, False, True),
     ("c3d_k3_24to40", (1, 24, 5, 16, 16), 40, 3, 1, 1, 0, False, False),
+    # ... with ONE depth tap (mygan's (1,3,3) 32 -> 57 factor): the item's second plane is masked off
+    ("c3d_k133_32to57", (2, 32, 4, 11, 17), 57, (1, 3, 3), 1, (0, 1, 1), 0, False, True),
+    ("c2d_k3_24to64", (3, 24, 20, 24), 64, 3, 1, 1, 0, False, False),
 ]
 
 

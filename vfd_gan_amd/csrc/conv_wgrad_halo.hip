@@ -239,10 +239,12 @@ int vfd_wgrad_halo_geom(const vfd_conv_desc* d, int* nsplit, size_t* bytes, WhGe
   if (d->Do != d->Di || d->Ho != d->Hi || d->Wo != d->Wi) return 0;
   // S = dy, G = x (regular) or S = x, G = dy (transposed): same grid either way
   const int Cs = d->transposed ? d->Cin : d->Cout, Cg = d->transposed ? d->Cout : d->Cin;
-  // gathered side with <= 32 channels: two depth taps per work item instead (kd == 3 only: with one depth tap half of the
-  // accumulator tile would stay empty); thinner S operands would leave most of the 64-row tile empty
+  // gathered side with <= 32 channels: two depth taps per work item instead.  With ONE depth tap (the (1,3,3) factor of a
+  // (2+1)D block, mygan's 32 -> 57 layers) the second plane of the item is masked off and half of the accumulator tile idles —
+  // those layers are bound by the per-tap gather of conv_wgrad (352 us for 0.4 GB), not by MFMA time, so the halo staging
+  // still pays.  Thinner S operands would leave most of the 64-row tile empty
   const bool g32 = Cg <= 32;
-  if (Cs < 33 || Cg < 17 || (g32 && d->kd != 3)) return 0;
+  if (Cs < 33 || Cg < 17) return 0;
   const int nrt = (Cs + 63) / 64, nct = g32 ? 1 : (cpad(Cg) + 63) / 64;
   const int nhb = (d->Hi + 7) / 8, nwb = (d->Wi + 15) / 16;
   const long long nblocks = (long long)d->N * d->Di * nhb * nwb;
