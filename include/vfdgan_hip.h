@@ -147,7 +147,8 @@ int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const void* pack
  * reads.  vfd_bn_backward_apply_sums finishes the BatchNorm backward from (g, sums).  bf16 with more than 32 output
  * channels only; no bias, no activation of its own, no split-K, no workspace. */
 int vfd_conv_bn_backward_supported(const vfd_conv_desc* d);   /* possible AND worth it: Cout >= the threshold below */
-int vfd_conv_set_bn_handover_min_channels(int c);              /* default 129 (measured break-even); returns the previous value */
+int vfd_conv_set_bn_handover_min_channels(int c);              /* default: never (measured: no gain once the reduce pass overlaps the
+                                                                  side-stream filter gradients); returns the previous value */
 int vfd_conv_forward_bn_backward(const vfd_conv_desc* d, const void* x, const void* packed, void* y, const void* bn_x,
                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                  float slope, float* sums, size_t sums_bytes, void* stream);

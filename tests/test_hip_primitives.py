@@ -246,7 +246,7 @@ def test_sequential_batchnorm_gradient_handover(nd, dev):
             origs = {nm: _count_calls(lib, nm, calls) for nm in names}
             old = vnn._NO_HANDOVER
             vnn._NO_HANDOVER = mode == "unfused"
-            old_minc = lib.vfd_conv_set_bn_handover_min_channels(33)      # default: 129, where the hand-over starts to pay
+            old_minc = lib.vfd_conv_set_bn_handover_min_channels(33)      # default: off (no gain once the reduce pass overlaps the side stream)
             try:
                 xd = x.to(dev).requires_grad_()
                 y = mine(F.to_cl(xd, dt)).to_torch()

@@ -349,7 +349,8 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
     if (d->transposed && (s[i] > 4 || (k[i] + s[i] - 1) / s[i] > 3)) return 0;
     if (!d->transposed && k[i] > 3) return 0;
   }
-  if (d->Cout > 64 || d->Cin < 25) return 0;      // wider outputs: conv_igemm's 128/256-channel tiles; thin inputs: conv_small / igemm
+  static const int max_cout = getenv("VFD_HALO_MAX_COUT") ? atoi(getenv("VFD_HALO_MAX_COUT")) : 64;      // tuning: channel tiles of 64 beyond the first
+  if (d->Cout > max_cout || d->Cin < 25) return 0;      // wider outputs: conv_igemm's 128/256-channel tiles; thin inputs: conv_small / igemm
   HaloP p;
   p.x = x; p.w = packed;
   p.e.y = y; p.e.bias = bias; p.e.stats = stats; p.e.Cop = cpad(d->Cout); p.e.Cout = d->Cout; p.e.act = d->act; p.e.slope = d->slope;

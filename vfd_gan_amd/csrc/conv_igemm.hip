@@ -711,17 +711,21 @@ extern "C" int vfd_conv_forward_mul(const vfd_conv_desc* d, const void* x, const
 
 // the BatchNorm hand-over needs the row-store epilogue (conv_epilogue.hpp, VIA_LDS): bf16 tiles of >= 64 channels, which
 // is what every dispatch path (conv_halo, conv_igemm) picks for more than 32 output channels
-// ... and pays from 129 channels on (measured, ganomaly 512 frames: the 256-channel tile's epilogue grows by what the
-// separate reduce pass cost, 30 us, and two launches go; the 128- and 64-channel tiles grow by 78 / 150 us against a
-// 60 / 100 us reduce pass: all workgroups reach their epilogues together, so the extra read is an HBM burst nothing hides)
+// ... but it is OFF by default (threshold "never"; vfd_conv_set_bn_handover_min_channels / VFD_BN_HANDOVER_MIN_C turn it on
+// from a channel count).  Measured on ganomaly, 512 frames: the 256-channel tile's epilogue grows by what the separate
+// reduce pass cost (30 us: a tie, two launches fewer), the 128- and 64-channel tiles grow by 78 / 150 us against a 60 /
+// 100 us reduce pass — all workgroups reach their epilogues together, so the extra read is an HBM burst nothing hides — and
+// since the filter gradients moved to a side stream the separate reduce pass overlaps with them: step 11.28 ms without
+// the hand-over, 11.33 with it from 129 channels on.
 static int g_bn_handover_min_c = -1;
+static const int BN_HANDOVER_NEVER = 1 << 30;
 extern "C" int vfd_conv_set_bn_handover_min_channels(int c) {
-  const int prev = g_bn_handover_min_c < 0 ? 129 : g_bn_handover_min_c;
+  const int prev = g_bn_handover_min_c < 0 ? BN_HANDOVER_NEVER : g_bn_handover_min_c;
   g_bn_handover_min_c = c < 33 ? 33 : c;
   return prev;
 }
 extern "C" int vfd_conv_bn_backward_supported(const vfd_conv_desc* d) {
-  if (g_bn_handover_min_c < 0) g_bn_handover_min_c = getenv("VFD_BN_HANDOVER_MIN_C") ? atoi(getenv("VFD_BN_HANDOVER_MIN_C")) : 129;
+  if (g_bn_handover_min_c < 0) g_bn_handover_min_c = getenv("VFD_BN_HANDOVER_MIN_C") ? atoi(getenv("VFD_BN_HANDOVER_MIN_C")) : BN_HANDOVER_NEVER;
   if (g_bn_handover_min_c < 33) g_bn_handover_min_c = 33;
   return d != nullptr && d->dtype == VFD_BF16 && d->Cout >= g_bn_handover_min_c;
 }
