@@ -25,7 +25,7 @@ CASES = [
     ("c3d_k3_86to40", (1, 86, 5, 7, 18), 40, 3, 1, 1, 0, False, True),           # partial last chunk (88 = 2*32 + 24), Cout 40
     ("c3d_k133_96to50", (2, 96, 3, 10, 16), 50, (1, 3, 3), 1, (0, 1, 1), 0, False, True),
     ("c3d_k311_40to64", (1, 40, 9, 6, 16), 64, (3, 1, 1), 1, (1, 0, 0), 0, False, False),
-    ("c3d_k111_64to24", (1, 64, 4, 8, 16), 24, 1, 1, 0, 0, False, True),
+    ("c3d_k111_40to24", (1, 40, 4, 8, 16), 24, 1, 1, 0, 0, False, True),      # (1x1x1 over 16/24/32/48/64 channels is conv_cin8's)
     ("c2d_k3_64to64", (3, 64, 20, 24), 64, 3, 1, 1, 0, False, True),             # frames: 1 x 16 x 16 tile
     ("c2d_k3_48to20", (2, 48, 17, 30), 20, 3, 1, 1, 0, False, False),
     ("t3d_k3s1_128to64", (1, 128, 4, 8, 16), 64, 3, 1, 1, 0, True, True),        # anogan NetG layer3[1]

@@ -56,6 +56,15 @@ CONV_CASES = [
     ("K4_cin8_k111_3to2", (2, 3, 4, 24, 24), 2, 1, 1, 0, 0, False, True),
     ("K5_cin8_T_k3s1_1to32", (1, 1, 6, 20, 20), 32, 3, 1, 1, 0, True, True),
     ("K5_cin8_T_k311s1_2to21", (1, 2, 6, 12, 12), 21, (3, 1, 1), 1, (1, 0, 0), 0, True, False),
+    # pointwise (1x1x1) factors over 9..32 channels (bf16: conv_cin8 on the granule row, conv_small.hip), forward, transposed
+    # (the data gradient form), with bias; 14 -> 32, 32 -> 14, 24 -> 27, 32 -> 54 as in mygan's discriminators
+    ("K4_pw_k111_14to32", (2, 14, 3, 10, 12), 32, 1, 1, 0, 0, False, True),
+    ("K4_pw_T_k111_32to14", (2, 32, 3, 10, 12), 14, 1, 1, 0, 0, True, False),
+    ("K4_pw_k111_24to27", (1, 24, 2, 9, 7), 27, 1, 1, 0, 0, False, True),
+    ("K4_pw_k111_32to54", (1, 32, 4, 12, 12), 54, 1, 1, 0, 0, False, False),
+    ("K4_pw_k111_64to54", (2, 64, 2, 9, 12), 54, 1, 1, 0, 0, False, True),
+    ("K4_pw_T_k111_54to64", (1, 54, 2, 9, 12), 64, 1, 1, 0, 0, True, False),      # CPAD(54) = 56: not a granule patch -> conv_igemm
+    ("K4_pw_T_k111_48to40", (1, 48, 2, 9, 12), 40, 1, 1, 0, 0, True, True),
 ]
 
 

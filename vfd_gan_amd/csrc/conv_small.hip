@@ -417,6 +417,36 @@ bool small_enabled() {
 int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
                        bool query, hipStream_t st) {
   if (!small_enabled() || d->dtype != VFD_BF16) return 0;
+  {
+    // Pointwise (1x1x1, stride 1) convolutions over 9..32 input channels — the k = 1 factors of the (2+1)D blocks whose other
+    // factor is (1,3,3) or (3,1,1), forward and data gradient (a transposed 1x1x1 convolution is the same operation on the
+    // A/B-swapped packing) — are conv_cin8 problems in disguise: a pixel's CPAD(Cin) channels are CPAD(Cin)/8 consecutive
+    // 8-channel granules, i.e. a row of kw' = CPAD(Cin)/8 "pixels" of a one-row, 8-channel image, convolved with a 1 x 1 x kw'
+    // filter at stride kw'.  The packed filter [Cout][1][CPAD(Cin)] IS [Cout][kw'][8], and a wave's 16 output pixels read one
+    // contiguous run of 16 x CPAD(Cin) x 2 bytes.  (conv_igemm ran these at 1.5 TB/s: one 64-byte K-step per tile.)
+    const int cip = cpad(d->Cin);
+    const bool unit = d->kd == 1 && d->kh == 1 && d->kw == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->pd == 0 && d->ph == 0 && d->pw == 0 &&
+                      d->Do == d->Di && d->Ho == d->Hi && d->Wo == d->Wi;
+    if (unit && cip > 8 && cip <= 32 && d->Cout <= 16 * CIN8_NI) {
+      const long long P = (long long)d->N * d->Di * d->Hi * d->Wi;
+      const int kwv = cip / 8;
+      if (P * kwv >= 0x7fffffffLL) return 0;
+      vfd_conv_desc v = *d;
+      v.N = 1; v.Di = 1; v.Hi = 1; v.Wi = (int)(P * kwv); v.Do = 1; v.Ho = 1; v.Wo = (int)P;
+      v.Cin = 8; v.kw = kwv; v.sw = kwv; v.transposed = 0;
+      return vfd_conv_small_try(&v, x, packed, bias, y, stats, query, st);
+    }
+    // 48 / 64 channels: 6 / 8 granules per pixel = a 2 x 3 / 2 x 4 patch of a [2P][3|4]-granule image, stride (2, 3|4)
+    if (unit && (cip == 48 || cip == 64) && d->Cout <= 16 * CIN8_NI) {
+      const long long P = (long long)d->N * d->Di * d->Hi * d->Wi;
+      const int kwv = cip / 16;
+      if (2 * P >= 0x7fffffffLL) return 0;
+      vfd_conv_desc v = *d;
+      v.N = 1; v.Di = 1; v.Hi = (int)(2 * P); v.Wi = kwv; v.Do = 1; v.Ho = (int)P; v.Wo = 1;
+      v.Cin = 8; v.kh = 2; v.kw = kwv; v.sh = 2; v.sw = kwv; v.transposed = 0;
+      return vfd_conv_small_try(&v, x, packed, bias, y, stats, query, st);
+    }
+  }
   const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
   // a stride-1 transposed convolution without output padding is a regular one with reversed taps and pad k-1-p
   const bool flip = d->transposed && d->sd == 1 && d->sh == 1 && d->sw == 1 && Cip == 8 &&
