@@ -65,6 +65,12 @@ CONV_CASES = [
     ("K4_pw_k111_64to54", (2, 64, 2, 9, 12), 54, 1, 1, 0, 0, False, True),
     ("K4_pw_T_k111_54to64", (1, 54, 2, 9, 12), 64, 1, 1, 0, 0, True, False),      # CPAD(54) = 56: not a granule patch -> conv_igemm
     ("K4_pw_T_k111_48to40", (1, 48, 2, 9, 12), 40, 1, 1, 0, 0, True, True),
+    # ... and the temporal (3,1,1) factors (depth taps x granules), regular and as stride-1 data gradients (depth taps reversed)
+    ("K3_gr_k311_21to32", (2, 21, 5, 8, 12), 32, (3, 1, 1), 1, (1, 0, 0), 0, False, True),
+    ("K3_gr_k311_27to64", (1, 27, 4, 9, 10), 64, (3, 1, 1), 1, (1, 0, 0), 0, False, False),
+    ("K3_gr_T_k311_32to21", (2, 32, 5, 8, 12), 21, (3, 1, 1), 1, (1, 0, 0), 0, True, True),
+    ("K3_gr_T_k311_64to27", (1, 64, 4, 9, 10), 27, (3, 1, 1), 1, (1, 0, 0), 0, True, False),
+    ("K3_gr_k311s2_24to40", (1, 24, 6, 6, 8), 40, (3, 1, 1), (2, 1, 1), (1, 0, 0), 0, False, False),
 ]
 
 

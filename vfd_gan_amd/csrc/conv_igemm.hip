@@ -665,7 +665,7 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
   }
   float dummy_stats;
   if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0 ? &dummy_stats : nullptr, true, nullptr) > 0) {
-    const bool pointwise = dn.kd == 1 && dn.kh == 1 && dn.kw == 1;      // conv_small.hip: 1x1x1 over <= 32 channels runs on conv_cin8
+    const bool pointwise = dn.kh == 1 && dn.kw == 1;      // conv_small.hip: (kd,1,1) filters over 16..64 channels run on conv_cin8
     snprintf(buf, n, "%s<%s>", (cpad(dn.Cin) == 8 || pointwise) ? "conv_cin8" : "convt_thin", t);
     return VFD_OK;
   }

@@ -33,7 +33,8 @@ struct Cin8P {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int act;
   float slope;
-  int flip;             // 1: stride-1 transposed convolution = regular convolution with the taps reversed and pad k-1-p
+  int flip;             // stride-1 transposed convolution = regular convolution with the taps reversed and pad k-1-p;
+                        // bit 0 / 1 / 2: reverse the depth / row / column taps (7 = all; 1 = depth only, see the granule remap)
   FastDiv fWo, fHo, fDo;
   long long M;          // output pixels
   int ntiles;           // tiles of CIN8_TILE pixels
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
     const int co = fi * 16 + (l & 15), kz = ks / p.kh, ky = ks - kz * p.kh, kx = l >> 4;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (co < p.Cout && kx < p.kw) {
-      const int fz = p.flip ? p.kd - 1 - kz : kz, fy = p.flip ? p.kh - 1 - ky : ky, fx = p.flip ? p.kw - 1 - kx : kx;
+      const int fz = (p.flip & 1) ? p.kd - 1 - kz : kz, fy = (p.flip & 2) ? p.kh - 1 - ky : ky, fx = (p.flip & 4) ? p.kw - 1 - kx : kx;
       v = *reinterpret_cast<const uint4*>(p.w + ((size_t)co * (p.kd * p.kh * p.kw) + (fz * p.kh + fy) * p.kw + fx) * 8);
     }
     *reinterpret_cast<uint4*>(smem + (size_t)f * 16) = v;
@@ -414,42 +415,52 @@ bool small_enabled() {
 }  // namespace
 
 // Returns 1 when the layer was handled (or, with `query`, would be), 0 when it is not one of the two shapes, < 0 on error.
+static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+                          bool query, hipStream_t st, int force_flip);
+
 int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
                        bool query, hipStream_t st) {
   if (!small_enabled() || d->dtype != VFD_BF16) return 0;
   {
-    // Pointwise (1x1x1, stride 1) convolutions over 9..32 input channels — the k = 1 factors of the (2+1)D blocks whose other
-    // factor is (1,3,3) or (3,1,1), forward and data gradient (a transposed 1x1x1 convolution is the same operation on the
-    // A/B-swapped packing) — are conv_cin8 problems in disguise: a pixel's CPAD(Cin) channels are CPAD(Cin)/8 consecutive
-    // 8-channel granules, i.e. a row of kw' = CPAD(Cin)/8 "pixels" of a one-row, 8-channel image, convolved with a 1 x 1 x kw'
-    // filter at stride kw'.  The packed filter [Cout][1][CPAD(Cin)] IS [Cout][kw'][8], and a wave's 16 output pixels read one
-    // contiguous run of 16 x CPAD(Cin) x 2 bytes.  (conv_igemm ran these at 1.5 TB/s: one 64-byte K-step per tile.)
-    const int cip = cpad(d->Cin);
-    const bool unit = d->kd == 1 && d->kh == 1 && d->kw == 1 && d->sd == 1 && d->sh == 1 && d->sw == 1 && d->pd == 0 && d->ph == 0 && d->pw == 0 &&
-                      d->Do == d->Di && d->Ho == d->Hi && d->Wo == d->Wi;
-    if (unit && cip > 8 && cip <= 32 && d->Cout <= 16 * CIN8_NI) {
-      const long long P = (long long)d->N * d->Di * d->Hi * d->Wi;
-      const int kwv = cip / 8;
-      if (P * kwv >= 0x7fffffffLL) return 0;
+    // Convolutions with NO in-plane taps — (kd,1,1) filters: the pointwise (1x1x1) and the temporal (3,1,1) factors of the
+    // (2+1)D blocks, forward and, at stride 1, their data gradients — over 16 / 24 / 32 / 48 / 64 input channels are conv_cin8
+    // problems in disguise: a pixel's CPAD(Cin) channels are g = CPAD(Cin)/8 consecutive 8-channel granules, and with no taps
+    // along H and W a plane of H x W pixels is one row of H*W*g "pixels" of an 8-channel image, convolved with a kd x 1 x g
+    // filter at stride g (g = 6 / 8: a 2 x 3 / 2 x 4 patch of a [2 H W][3|4] image at stride (2, 3|4)).  The packed filter
+    // [Cout][kd][CPAD(Cin)] IS [Cout][kd][g][8], and a wave's 16 output pixels read one contiguous run per depth tap.
+    // (conv_igemm / conv_halo ran these at 1.5 TB/s: one or three 64-byte K-steps per tile.)  A transposed stride-1 form
+    // reverses the DEPTH taps only (flip mask 1) — the granule "taps" are channels.
+    const int cip = cpad(d->Cin), g = cip / 8;
+    const bool noplane = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 && d->Ho == d->Hi && d->Wo == d->Wi;
+    const bool patch = cip == 48 || cip == 64;
+    const bool tr_ok = d->transposed && d->sd == 1 && d->Do == d->Di + d->kd - 1 - 2 * d->pd && d->kd - 1 - d->pd >= 0;
+    if (noplane && (!d->transposed || tr_ok) && d->kd <= 4 && ((cip > 8 && cip <= 32) || patch) && d->Cout <= 16 * CIN8_NI) {
+      const long long plane = (long long)d->Hi * d->Wi;
+      if (plane * (patch ? 2 : g) >= 0x7fffffffLL) return 0;
       vfd_conv_desc v = *d;
-      v.N = 1; v.Di = 1; v.Hi = 1; v.Wi = (int)(P * kwv); v.Do = 1; v.Ho = 1; v.Wo = (int)P;
-      v.Cin = 8; v.kw = kwv; v.sw = kwv; v.transposed = 0;
-      return vfd_conv_small_try(&v, x, packed, bias, y, stats, query, st);
-    }
-    // 48 / 64 channels: 6 / 8 granules per pixel = a 2 x 3 / 2 x 4 patch of a [2P][3|4]-granule image, stride (2, 3|4)
-    if (unit && (cip == 48 || cip == 64) && d->Cout <= 16 * CIN8_NI) {
-      const long long P = (long long)d->N * d->Di * d->Hi * d->Wi;
-      const int kwv = cip / 16;
-      if (2 * P >= 0x7fffffffLL) return 0;
-      vfd_conv_desc v = *d;
-      v.N = 1; v.Di = 1; v.Hi = (int)(2 * P); v.Wi = kwv; v.Do = 1; v.Ho = (int)P; v.Wo = 1;
-      v.Cin = 8; v.kh = 2; v.kw = kwv; v.sh = 2; v.sw = kwv; v.transposed = 0;
-      return vfd_conv_small_try(&v, x, packed, bias, y, stats, query, st);
+      v.Cin = 8;
+      v.transposed = 0;
+      if (d->transposed) v.pd = d->kd - 1 - d->pd;      // the regular form of the stride-1 transposed convolution
+      if (!patch) {
+        v.Hi = 1; v.Wi = (int)(plane * g); v.Ho = 1; v.Wo = (int)plane;
+        v.kw = g; v.sw = g;
+      } else {
+        v.Hi = (int)(2 * plane); v.Wi = g / 2; v.Ho = (int)plane; v.Wo = 1;
+        v.kh = 2; v.kw = g / 2; v.sh = 2; v.sw = g / 2;
+      }
+      return small_try_impl(&v, x, packed, bias, y, stats, query, st, d->transposed ? 1 : 0);
     }
   }
+  return small_try_impl(d, x, packed, bias, y, stats, query, st, -1);
+}
+
+// force_flip < 0: the tap reversal follows from the descriptor (a stride-1 transposed convolution over <= 8 channels: all
+// three axes); >= 0: the descriptor is already the regular form and force_flip is the tap-reversal mask
+static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+                          bool query, hipStream_t st, int force_flip) {
   const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
   // a stride-1 transposed convolution without output padding is a regular one with reversed taps and pad k-1-p
-  const bool flip = d->transposed && d->sd == 1 && d->sh == 1 && d->sw == 1 && Cip == 8 &&
+  const bool flip = force_flip < 0 && d->transposed && d->sd == 1 && d->sh == 1 && d->sw == 1 && Cip == 8 &&
                     d->Do == d->Di + d->kd - 1 - 2 * d->pd && d->Ho == d->Hi + d->kh - 1 - 2 * d->ph && d->Wo == d->Wi + d->kw - 1 - 2 * d->pw &&
                     d->kd - 1 - d->pd >= 0 && d->kh - 1 - d->ph >= 0 && d->kw - 1 - d->pw >= 0;
   if (!d->transposed || flip) {
@@ -467,7 +478,7 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
     p.N = d->N; p.Di = d->Di; p.Hi = d->Hi; p.Wi = d->Wi; p.Do = d->Do; p.Ho = d->Ho; p.Wo = d->Wo;
     p.Cout = d->Cout; p.Cop = Cop;
     p.kd = d->kd; p.kh = d->kh; p.kw = d->kw; p.sd = d->sd; p.sh = d->sh; p.sw = d->sw; p.pd = d->pd; p.ph = d->ph; p.pw = d->pw;
-    p.flip = flip ? 1 : 0;
+    p.flip = force_flip >= 0 ? force_flip : (flip ? 7 : 0);
     if (flip) { p.pd = d->kd - 1 - d->pd; p.ph = d->kh - 1 - d->ph; p.pw = d->kw - 1 - d->pw; }
     p.act = d->act; p.slope = d->slope;
     p.fWo = make_fastdiv((uint32_t)d->Wo); p.fHo = make_fastdiv((uint32_t)d->Ho); p.fDo = make_fastdiv((uint32_t)d->Do);
