@@ -177,10 +177,13 @@ int vfd_wgrad_workspace(const vfd_conv_desc* d, int32_t* nsplit, size_t* bytes);
 int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void* dy, void* ws, size_t ws_bytes,
                    void* stream);
 int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream);
-/* ... and, in the same launch, db[Cout] += the fold of bias_rep[VFD_STATS_REPLICAS][CPAD(Cout)] (see
- * vfd_bn_backward_apply_sums: the layer's bias gradient when a BatchNorm consumes its output).                   */
+/* ... and, in the same launch, db[Cout] += the fold of VFD_STATS_REPLICAS replica rows bias_rep[r * rep_stride + c]: the
+ * layer's bias gradient = the column sums of its output gradient, left there by whoever produced that gradient — the
+ * consuming BatchNorm's apply pass (vfd_bn_backward_apply_sums, rep_stride = CPAD(Cout)) or the consuming convolution's
+ * data-gradient launch run with a statistics buffer (conv -> conv chains, models/anogan.py:51-52,85-86: the sum row of
+ * [VFD_STATS_REPLICAS][2][CPAD(Cout)], rep_stride = 2 * CPAD(Cout)).                                              */
 int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
-                          float* db, void* stream);
+                          int rep_stride, float* db, void* stream);
 /* Dispatch switch of the halo-tiled filter-gradient kernel (conv_wgrad_halo.hip: stride-1 layers with a 3 x 3 in-plane
  * footprint, kd 1 or 3, >= 33 channels on both sides, bf16): 0 = default rules, 1 = never (conv_wgrad's per-tap
  * gather), 2 = whenever eligible (tests).  Returns the previous mode.  vfd_wgrad_workspace / vfd_conv_wgrad /

@@ -698,3 +698,55 @@ def test_upsample_cat_fused(dt, dev):
     assert relerr(y, yr) < tol
     assert relerr(xd.grad, xr.grad) < tol * (1 if dt == torch.float32 else 2), relerr(xd.grad, xr.grad)
     assert relerr(sd.grad, sr.grad) < tol
+
+
+def test_conv_to_conv_bias_gradient_from_data_gradient_statistics(dev):
+    """conv(bias) -> conv with nothing in between (anogan NetG's ConvTranspose3d -> Conv3d pairs, models/anogan.py:51-52; NetD's
+    Conv3d -> Conv3d, :85-86): the first layer's bias gradient is the column sum of the second layer's data gradient, taken
+    as that launch's epilogue statistics and folded by the first layer's wgrad_reduce launch — no vfd_bias_grad pass.  bf16,
+    against torch (these bias gradients are real, not rounding noise)."""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import _lib, functional as F
+    torch.manual_seed(41)
+    dt = torch.bfloat16
+    spec = lambda M: [M.ConvTranspose3d(40, 24, 3, 1, 1), M.Conv3d(24, 48, 3, 1, 1), M.Conv3d(48, 40, (1, 3, 3), 1, (0, 1, 1)),      # noqa: E731
+                      M.BatchNorm3d(40), M.LeakyReLU(0.2), M.Conv3d(40, 8, 1, 1, 0)]
+    ref = torch.nn.Sequential(*spec(torch.nn))
+    with torch.no_grad():
+        for prm in ref.parameters():
+            prm.copy_(prm.bfloat16().float())
+    x = _rand((2, 40, 4, 10, 12), 91).bfloat16().float()
+    state0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    gy = _rand(tuple(yr.shape), 92)
+    yr.backward(gy)
+    from vfd_gan_amd import optim
+    mine = vnn.Sequential(*spec(vnn))
+    mine.load_state_dict(state0)
+    mine.to(dev)
+    opt = optim.Adam(mine.parameters(), lr=1e-3)      # arena gradients: the fused path accumulates straight into them
+    opt.zero_grad()
+    lib = _lib.load()
+    calls = {}
+    origs = {nm: _count_calls(lib, nm, calls) for nm in ("vfd_bias_grad", "vfd_wgrad_reduce_bias")}
+    try:
+        xd = x.to(dev).requires_grad_()
+        y = mine(F.to_cl(xd, dt)).to_torch()
+        y.backward(gy.to(dev))
+        F.join_side_stream()
+        torch.cuda.synchronize()
+    finally:
+        for nm, o in origs.items():
+            setattr(lib, nm, o)
+    # biases of layers 0 and 1 come from their consumers' data-gradient statistics, layer 2's from the BatchNorm apply pass;
+    # only the last conv's bias needs the column-sum pass
+    assert calls.get("vfd_wgrad_reduce_bias", 0) == 3 and calls.get("vfd_bias_grad", 0) == 1, calls
+    tol = TOL[dt] * 2
+    assert relerr(y, yr) < tol
+    for (n, pm), pr in zip(mine.named_parameters(), ref.parameters()):
+        if n == "2.bias":
+            continue      # feeds a BatchNorm: zero up to rounding
+        e = relrms(pm.grad, pr.grad)
+        assert e < 0.06, (n, e)
+    assert relerr(mine[0].bias.grad, ref[0].bias.grad) < tol and relerr(mine[1].bias.grad, ref[1].bias.grad) < tol

@@ -267,13 +267,13 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
 // the parameter's gradient db[Cb] (vfd_bn_backward_apply_sums; a separate fold launch would cost as much as it does).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B,
                                                            int T, int Bp, int nsplit, float beta, long long wblocks,
-                                                           const float* __restrict__ bias_rep, float* __restrict__ db, int Cb, int Cbp) {
+                                                           const float* __restrict__ bias_rep, float* __restrict__ db, int Cb, int rep_stride) {
   if ((long long)blockIdx.x >= wblocks) {
     const int c = (int)(blockIdx.x - wblocks) * 256 + threadIdx.x;
     if (c < Cb) {
       float v = 0.f;
 #pragma unroll
-      for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += bias_rep[(size_t)r * Cbp + c];
+      for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += bias_rep[(size_t)r * rep_stride + c];
       db[c] += v;
     }
     return;
@@ -452,7 +452,7 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
 }
 
 static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep, float* db,
-                               void* stream) {
+                               int rep_stride, void* stream) {
   WgGeom g;
   int rc = make_geom(d, g);
   if (rc != VFD_OK) return rc;
@@ -462,17 +462,18 @@ static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw
   const int extra = bias_rep != nullptr ? (d->Cout + 255) / 256 : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta, blocks, bias_rep, db, d->Cout,
-                     cpad(d->Cout));
+                     rep_stride);
   VFD_CHECK_LAUNCH("wgrad_reduce");
   return VFD_OK;
 }
 
 extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream) {
-  return wgrad_reduce_launch(d, ws, dw, beta, nullptr, nullptr, stream);
+  return wgrad_reduce_launch(d, ws, dw, beta, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
-                                     float* db, void* stream) {
+                                     int rep_stride, float* db, void* stream) {
   VFD_REQUIRE(d && bias_rep && db, "wgrad_reduce_bias: null pointer");
-  return wgrad_reduce_launch(d, ws, dw, beta, bias_rep, db, stream);
+  VFD_REQUIRE(rep_stride >= cpad(d->Cout), "wgrad_reduce_bias: replica rows of %d floats are shorter than CPAD(Cout)", rep_stride);
+  return wgrad_reduce_launch(d, ws, dw, beta, bias_rep, db, rep_stride, stream);
 }

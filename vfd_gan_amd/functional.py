@@ -504,7 +504,7 @@ class _Conv(torch.autograd.Function):
     gradient through the same kernel with swapped roles + split-K filter gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, stats, in_act, out_act, bias_token=None):
+    def forward(ctx, x, weight, bias, geom, stats, in_act, out_act, bias_token=None, in_bias_token=None):
         (Cin, Cout, k, s, p, out_dhw, transposed, act, slope) = geom
         x = x.contiguous()
         N = x.shape[0]
@@ -545,6 +545,9 @@ class _Conv(torch.autograd.Function):
                 ctx.in_act = (in_act["act"], in_act["slope"])
         ctx.out_act = out_act
         ctx.bias_token = bias_token
+        # `in_bias_token`: the conv (with a bias, nothing in between) that produced x asks for the column sums of THIS layer's
+        # data gradient — its bias gradient — which the data-gradient launch can take as its epilogue "statistics"
+        ctx.in_bias_token = in_bias_token
         ctx.save_for_backward(x, weight, out if act != _lib.ACT_NONE else None)
         return out
 
@@ -579,7 +582,14 @@ class _Conv(torch.autograd.Function):
                 packed = _packed_filter(weight, dt, transpose_ab=not transposed, A=A, B=B, T=T)
                 gx = torch.empty_like(x)
                 desc = _make_desc(N, out_dhw, Cout, in_dhw, Cin, k, s, p, not transposed, dt)
-                _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
+                itok = ctx.in_bias_token
+                if itok is not None and ctx.in_act is None and ctx.in_bn is None:
+                    # the sum row of the epilogue statistics of gx = the producer conv's bias gradient (folded by its own
+                    # vfd_wgrad_reduce_bias): no separate column-sum pass over gx
+                    _conv_launch(desc, gy, packed, None, gx, stats=itok["rep"])
+                    itok["taken"] = True
+                else:
+                    _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
         if ctx.needs_input_grad[1] and not frozen:
             desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
@@ -611,7 +621,7 @@ class _Conv(torch.autograd.Function):
                     # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias
                     # gradient) in replica rows: folded by the same launch
                     check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
-                                                    bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
+                                                    int(tok.get("stride", cpad(Cout))), bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
                     bias_done = True
                 elif direct is not None:
                     check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
@@ -629,11 +639,11 @@ class _Conv(torch.autograd.Function):
                 gb = torch.empty(Cout, dtype=torch.float32, device=x.device)
                 check(lib.vfd_bias_grad(dtype_code(dt), gy.data_ptr(), gb.data_ptr(), rows_out, Cout, 0.0, bws.data_ptr(),
                                         stream()), "bias_grad")
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, act=_lib.ACT_NONE, slope=0.0,
-         stats=None, claim_act_grad=False, bias_token=None):
+         stats=None, claim_act_grad=False, bias_token=None, in_bias_token=None):
     """Convolution on a ClTensor.  `weight` is the torch-layout float32 parameter ([Cout,Cin,k..] or, transposed,
     [Cin,Cout,k..]); Linear layers pass a [out,in] matrix with x.nsp == 0."""
     nsp = x.nsp
@@ -661,7 +671,7 @@ def conv(x, weight, bias, stride, padding, output_padding=0, transposed=False, a
     geom = (Cin, Cout, k, s, p, out_dhw, bool(transposed), act, float(slope))
     in_act = (x.fused_act or x.fused_bn) if claim_act_grad else None
     out_act = {"claimed": False, "act": act, "slope": float(slope)} if act != _lib.ACT_NONE else None
-    out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act, bias_token)
+    out = _Conv.apply(x.t, weight, bias, geom, stats, in_act, out_act, bias_token, in_bias_token)
     return ClTensor(out, Cout, nsp, out_act)
 
 

@@ -41,7 +41,7 @@ def _act_of(m):
 class _ConvMixin:
     _transposed = False
 
-    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None, claim_act_grad=False, bias_token=None):
+    def forward(self, x, act=_lib.ACT_NONE, slope=0.0, stats=None, claim_act_grad=False, bias_token=None, in_bias_token=None):
         _need_cl(x, type(self).__name__)
         if self.groups != 1 or any(d != 1 for d in self.dilation):
             raise NotImplementedError("groups/dilation are not used by the reference nets")
@@ -49,7 +49,7 @@ class _ConvMixin:
             raise NotImplementedError("padding_mode %r" % (self.padding_mode,))
         op = self.output_padding if self._transposed else 0
         return F.conv(x, self.weight, self.bias, self.stride, self.padding, op, self._transposed, act, slope, stats,
-                      claim_act_grad, bias_token)
+                      claim_act_grad, bias_token, in_bias_token)
 
 
 class Conv3d(_ConvMixin, tnn.Conv3d):
@@ -230,6 +230,8 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
                 if j > 0 and is_conv(j - 1):
                     need += F.stats_buffer_numel(m.num_features) * (2 if mods[j - 1].bias is not None else 1)
                 need += F.stats_buffer_numel(m.num_features)      # backward sums (every training BatchNorm)
+            if handover and is_conv(j) and m.bias is not None and is_conv(j + 1):
+                need += F.stats_buffer_numel(m.out_channels)      # conv(bias) -> conv: the first one's bias gradient
         if need:
             pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
             F.register_pool(pool)
@@ -271,6 +273,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
         give = handover and "bwd_sums" in kw and is_conv(nxt_i)
         return bn(x, sums=sums, **kw) if sums is not None else bn(x, **kw), nxt_i, give
 
+    chain_tok = None      # bias token handed from a conv (with bias) to the conv that directly consumes its output
     while i < n:
         m = mods[i]
         nxt = mods[i + 1] if i + 1 < n else None
@@ -279,6 +282,14 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
             # gradient takes that producer's backward into its epilogue (functional._Conv)
             kw = {"claim_act_grad": True} if (fresh and not isinstance(m, Linear) and not _NO_HANDOVER) else {}
             fresh = False
+            if chain_tok is not None:
+                kw["in_bias_token"] = chain_tok
+                chain_tok = None
+            if handover and pool is not None and is_conv(i) and m.bias is not None and is_conv(i + 1):
+                # conv(bias) -> conv with nothing in between: the consumer's data-gradient launch takes the column sums of
+                # its output (this layer's bias gradient) as epilogue statistics
+                chain_tok = {"taken": False, "rep": take(m.out_channels), "stride": 2 * F.cpad(m.out_channels)}
+                kw["bias_token"] = chain_tok
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
                 x = m(x, act=a[0], slope=a[1], **kw)
