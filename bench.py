@@ -2,7 +2,8 @@
 """Headline benchmark: video clips/sec per GAN step on MI355X (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W            [--model ganomaly|anogan|mygan]
-    (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...; started
+     plainly with --gpus N > 1 it launches exactly that itself, as a child process, before this process touches the GPU)
 
 Default workload (config.workload): BASELINE.json configs[1] — ganomaly, 16x112x112 clips, bf16 MFMA storage with f32
 accumulation / f32 master weights, batch 32 clips per GPU (= 512 frames of 3x112x112 through the 2-D nets).
@@ -18,7 +19,10 @@ from HIP events on the launch stream, taken in an eager pass of the same step ri
 (events cannot be recorded inside a replayed graph) with the stream kept GPU-bound (a device-side delay in front of
 every step lets the host run ahead, so an event pair brackets the kernel and not the host's launch gap);
 `cpu_baseline` times the oracle (the CPU restatement of the reference step, stock torch.nn float32) on this box's host
-cores on a bounded sample.
+cores on a bounded sample; `recon_parity` is BASELINE.json's "recon-MSE vs ref": the loss scalars of ONE step of the HIP
+path in float32 (north_star: <= 1e-4 relative) and in bf16 (reported) against that same oracle step on identical weights
+and clips; `secondary` (default workload, 1 GPU) carries the anogan (configs[2]) and mygan (configs[3], per-GPU share)
+clips/s and step MFMA fractions from short runs of the same harness.
 """
 import argparse
 import contextlib
@@ -109,47 +113,103 @@ def host_cores():
     return min(n, int(os.environ.get("VFD_CPU_BASELINE_CORES", "16")))
 
 
+def _p0(net):
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+
+
 def cpu_baseline(model, isize, nfr):
-    """The oracle step on the host cores, bounded sample (~10-30 s): 1 warm-up + a few timed steps on a few clips."""
+    """The oracle step on the host cores, bounded sample (~10-30 s): 1 warm-up + a few timed steps on a few clips.
+    Returns (baseline dict, parity context): the warm-up step doubles as the reference of recon_parity() — its loss
+    scalars, the weights it started from and its clips (Dropout off on both sides: the CPU and device RNG streams differ)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from vfd_gan_amd.lib.data import synthetic_batch, synthetic_flow
+    from vfd_oracle.weights import fill_module
     cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
+    ctx = {"model": model, "isize": isize, "nfr": nfr}
+    snap = lambda net: {k: v.clone() for k, v in net.state_dict().items()}    # noqa: E731
     if model == "ganomaly":
         from vfd_oracle import ganomaly as OG
         clips, steps = 16, 3
         opt = OG.make_opt(isize=isize)
-        og, od = OG.NetG(opt), OG.NetD(opt)
+        og, od = fill_module(OG.NetG(opt), 7), fill_module(OG.NetD(opt), 8)
+        ctx.update(sd_g=snap(og), sd_d=snap(od), clips=clips, batch=synthetic_batch(clips, nfr, isize, 3, seed=1234))
         opt_g, opt_d = OG.make_optimizers(og, od, opt)
-        x = OG.fold_frames(synthetic_batch(clips, nfr, isize, 3, seed=1234)[0])
-        run = lambda: OG.step(og, od, opt_g, opt_d, x, opt)    # noqa: E731
+        x = OG.fold_frames(ctx["batch"][0])
+        run = lambda: OG.step(og, od, opt_g, opt_d, x, opt)[0]    # noqa: E731
     elif model == "anogan":
         from vfd_oracle import anogan as OA
         clips, steps = 2, 2
-        og, od = OA.NetG(nfr, isize).train(), OA.NetD(nfr, isize).train()
+        og, od = fill_module(OA.NetG(nfr, isize), 7).train(), fill_module(OA.NetD(nfr, isize), 8).train()
+        _p0(og)
         g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
-        real, z = synthetic_batch(clips, nfr, isize, 3, seed=1234)[1], torch.randn(clips, 100)
-        run = lambda: OA.step(og, od, g_opt, d_opt, real, z)   # noqa: E731
+        batch, z = synthetic_batch(clips, nfr, isize, 3, seed=1234), torch.randn(clips, 100)
+        ctx.update(sd_g=snap(og), sd_d=snap(od), clips=clips, batch=batch, z=z)
+        run = lambda: OA.step(og, od, g_opt, d_opt, batch[1], z)[0]   # noqa: E731
     else:
         from vfd_oracle import mygannet as OM
         clips, steps = 2, 2
-        og, od = OM.NetG().train(), OM.NetD(OM.make_args(nfr, isize)).train()
+        og, od = fill_module(OM.NetG(), 7).train(), fill_module(OM.NetD(OM.make_args(nfr, isize)), 8).train()
+        _p0(og)
         opt_g, opt_d = OM.make_optimizers(og, od)
-        inp, _, gt, _ = synthetic_batch(clips, nfr, isize, 3, seed=1234)
+        batch = synthetic_batch(clips, nfr, isize, 3, seed=1234)
         gf, pf = synthetic_flow(clips, nfr, isize, 1), synthetic_flow(clips, nfr, isize, 2)
-        run = lambda: OM.step(og, od, opt_g, opt_d, inp, gt, gf, pf)    # noqa: E731
-    run()
+        ctx.update(sd_g=snap(og), sd_d=snap(od), clips=clips, batch=batch, gf=gf, pf=pf)
+        run = lambda: OM.step(og, od, opt_g, opt_d, batch[0], batch[2], gf, pf)[0]    # noqa: E731
+    ctx["ref"] = run()
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
     dt = (time.perf_counter() - t0) / steps
     return {"value": round(clips / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle %s step (stock torch.nn f32 on the host cores), %d clips of %dx%dx%d, 1 warm-up + %d "
-                      "timed steps (%.2f s/step)" % (model, clips, nfr, isize, isize, steps, dt)}
+                      "timed steps (%.2f s/step)" % (model, clips, nfr, isize, isize, steps, dt)}, ctx
 
 
-def main():
+RECON_KEY = {"ganomaly": "err_g_con", "anogan": "err_d", "mygan": "err_g_con"}      # L1 / BCE / weighted_bce (BASELINE.md section 3)
+
+
+def recon_parity(ctx, local):
+    """BASELINE.json metric, second half ("recon-MSE vs ref"): ONE optimize_params of the HIP path on the weights and clips
+    of the oracle's first step (cpu_baseline's warm-up step), float32 (north_star tolerance 1e-4 relative) and bf16 (the
+    benchmarked storage type: deviation reported, not gated).  The oracle is the checker here, nothing more."""
+    from vfd_gan_amd import functional as F
+    model, ref, out = ctx["model"], ctx["ref"], {}
+    prev = F.get_compute_dtype()
+    try:
+        for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            m = build_model(model, make_args(model, ctx["clips"], ctx["nfr"], ctx["isize"], local), dt)
+            m.netg.load_state_dict(ctx["sd_g"])
+            m.netd.load_state_dict(ctx["sd_d"])
+            _p0(m.netg)
+            F.invalidate_weight_cache()
+            if model == "mygan":
+                m.set_input(ctx["batch"], gt_flow=ctx["gf"], pre_flow=ctx["pf"])
+            else:
+                m.set_input(ctx["batch"])
+            if model == "anogan":
+                m.z = ctx["z"].to(m.device)
+            m.optimize_params(check_collapse=False) if model == "ganomaly" else m.optimize_params()
+            got = {k.split("/")[1]: v for k, v in m.errors().items()}
+            out[tag] = {k: abs(got[k] - v) / max(abs(v), 1e-12) for k, v in ref.items()}
+            out[tag + "_losses"] = {k: got[k] for k in ref}
+            del m
+            torch.cuda.empty_cache()
+    finally:
+        F.set_compute_dtype(prev)
+    key = RECON_KEY[model]
+    return {"recon_loss": key, "cpu_oracle": round(ref[key], 8), "hip_f32": round(out["f32_losses"][key], 8),
+            "recon_rel_err": float("%.3e" % out["f32"][key]), "recon_rel_err_bf16": float("%.3e" % out["bf16"][key]),
+            "worst_loss_rel_err_f32": float("%.3e" % max(out["f32"].values())), "worst_loss_rel_err_bf16": float("%.3e" % max(out["bf16"].values())),
+            "tolerance_f32": 1e-4,
+            "sample": "one optimize_params on %d clips of %dx%dx%d, weights and clips of the oracle's first step, Dropout off"
+                      % (ctx["clips"], ctx["nfr"], ctx["isize"], ctx["isize"])}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--model", default="ganomaly", choices=["ganomaly", "anogan", "mygan"])
@@ -164,22 +224,21 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying a hipGraph")
     ap.add_argument("--layers", action="store_true", help="print a per-geometry table of the MFMA kernels to stderr")
-    a = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short anogan / mygan runs of the default line's `secondary` key")
+    a = ap.parse_args(argv)
+    a.explicit = {k for k in ("batch", "isize") if getattr(a, k) is not None}      # (--steps / --warmup are the driver's to choose)
     for k, v in DEFAULTS[a.model].items():
         if getattr(a, k) is None:
             setattr(a, k, v)
+    return a
 
+
+def run_workload(a, rank, world, local, dev):
+    """Build the model, capture the step, time a.steps replays (barrier + synchronize on both sides, max over ranks) and
+    take the per-kernel pass.  Returns the JSON line's dict on rank 0, None elsewhere."""
     from vfd_gan_amd import dist as vdist
     from vfd_gan_amd import functional as F
     from vfd_gan_amd.lib.data import synthetic_batch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % a.gpus)
-    rank, world = vdist.init_from_env()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
-    dev = torch.device("cuda", torch.cuda.current_device())
     dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": "fp8"}[a.dtype]
 
     model = build_model(a.model, make_args(a.model, a.batch, a.nfr, a.isize, local), dtype)
@@ -271,6 +330,7 @@ def main():
     if world > 1:
         vdist.barrier()
 
+    out = None
     if rank == 0:
         clips_s = world * a.batch * a.steps / elapsed
         peak = MFMA_PEAK_F32_TFLOPS if a.dtype == "f32" else MFMA_PEAK_BF16_TFLOPS      # (fp8 mode: priced against bf16, most FLOPs stay bf16)
@@ -324,20 +384,64 @@ def main():
             net_us = max(raw_us - event_overhead_us, 0.5 * raw_us)
             tf = d["flops"] / d["launches"] / (net_us * 1e-6) / 1e12
             traffic = None      # HBM bytes per launch of this kernel from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE /
-            tpath = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % a.model)       # WRITE_SIZE runs: tools/profile_all.sh)
-            if a.dtype == "bf16" and os.path.exists(tpath):
+            tpaths = [os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (r_, a.model)) for r_ in ("r03", "r02")]      # WRITE_SIZE runs: tools/profile_all.sh)
+            tpath = next((t_ for t_ in tpaths if os.path.exists(t_)), None)
+            if a.dtype == "bf16" and tpath is not None:
                 traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": traffic,
                                "launches_per_step": d["launches"] // timer_steps,
-                               "timed_in": "eager single-stream pass after the timed region, stream kept GPU-bound by a device-side delay; rocprofv3 cross-check: profiles/r02_<model>_kernel_stats_single_stream.csv",
+                               "timed_in": "eager single-stream pass after the timed region, stream kept GPU-bound by a device-side delay; rocprofv3 cross-check: profiles/r03_<model>_kernel_stats_single_stream.csv",
+                               "traffic_from": os.path.relpath(tpath, ROOT) if (traffic is not None and tpath) else None,
                                "avg_launch_us": round(net_us, 2), "avg_launch_us_raw_events": round(raw_us, 2),
                                "event_pair_overhead_us": round(event_overhead_us, 2),
                                "avg_launch_gflop": round(d["flops"] / d["launches"] / 1e9, 3)}
             out["kernels"] = {k: {"launches_per_step": v["launches"] // timer_steps, "ms_per_step": round(v["ms"] / timer_steps, 3),
                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in sorted(summ.items())}
+    return out if rank == 0 else None
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one rank per GPU ourselves (fresh child processes through torch.distributed.run, exactly
+        # the driver's command line; THIS process has not touched the GPU and never will) and hand on rank 0's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
+    from vfd_gan_amd import dist as vdist
+    rank, world = vdist.init_from_env()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = run_workload(a, rank, world, local, dev)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    default_line = a.model == "ganomaly" and a.dtype == "bf16" and not a.explicit and a.nfr == 16
+    if rank == 0 and world == 1 and default_line and not a.no_secondary:
+        # the 3-D workloads of BASELINE.json on the same harness, bounded (10 timed replays each): configs[2] and configs[3]
+        out["secondary"] = {}
+        for name in ("anogan", "mygan"):
+            b = parse_args(["--model", name, "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"])
+            r = run_workload(b, rank, world, local, dev)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            out["secondary"][name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                      "steps": r["steps"], "step_mfma_frac": r.get("step_mfma_frac"),
+                                      "step_reference_mfma_frac": r["step_reference_mfma_frac"],
+                                      "dominant_kernel": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_us")} if "roofline" in r else None}
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.model, a.isize, a.nfr)
+            out["cpu_baseline"], ctx = cpu_baseline(a.model, a.isize, a.nfr)
+            out["recon_parity"] = recon_parity(ctx, local)
+            out["recon_rel_err"] = out["recon_parity"]["recon_rel_err"]
         print(json.dumps(out), flush=True)
     if vdist.is_initialized():      # world > 1, or the single-rank RCCL rehearsal (VFD_DIST_SINGLE=1)
         vdist.barrier()

@@ -165,6 +165,12 @@ int vfd_conv_kernel_name(const vfd_conv_desc* d, int want_stats, char* buf, size
  * to be flipped while launches are in flight on other threads. */
 int vfd_conv_set_halo_mode(int mode);
 
+/* Pixel extent of the 16-wave 256-channel conv_igemm tile (bf16, more than 128 output channels), in 16-pixel sub-tiles:
+ * 0 = chosen per layer (12..16, the count that minimises rounds x work per round on the device's CUs: conv_igemm.hip
+ * pick_tile_sub), 12..16 = forced (tests / A-B timing; 16 = the fixed 256-pixel tile of rounds 1-2).  Returns the previous
+ * setting.  Process-wide, like the switches above. */
+int vfd_conv_set_tile_sub(int sub);
+
 /* Filter gradient.  Computes, for the conv described by `d` (same desc as forward),
  *     dWp[r][t][c] = sum_{n,q} S[n,q][r] * G[n, q*s-p+t][c]
  * with (S,G) = (dy, x) for transposed = 0 and (x, dy) for transposed = 1, i.e. in the packed layout of

@@ -1,0 +1,268 @@
+"""bf16-FAITHFUL mode of the oracle (TEST INFRASTRUCTURE, like the rest of oracle/).
+
+The float32 oracle pins the arithmetic of the reference (models/{ganomaly,anogan,mygannet,spatiotempconv}.py); the
+benchmarked HIP path stores activations, packed filters and activation gradients in bfloat16 (float32 accumulation,
+float32 BatchNorm statistics, float32 master weights / Adam).  Against the float32 oracle that path can only be gated
+at ~5e-2: a bf16 forward deviates by ~1e-2, about 1 % of the activations land on the other side of a ReLU / LeakyReLU /
+L1 kink, and each such flip is an O(1) relative error of one gradient element in ANY bf16 implementation.
+
+This module re-runs the SAME oracle modules (same parameters, same step functions) with a round-to-bfloat16 placed at
+exactly the tensors the HIP path stores — and nowhere else:
+
+* every filter is used as ``w + (bf16(w) - w).detach()`` (the packed bf16 copy; the gradient reaches the float32 master
+  unrounded, as vfd_wgrad_reduce writes it),
+* a conv / linear output is rounded once, AFTER the epilogue that is fused into the kernel (bias, activation),
+* BatchNorm -> activation (-> AvgPool3d where vfd_gan_amd.nn.run_fused / models.mygannet._conv_bn_act fuse it) is rounded
+  once, after the last fused stage (the U-Net encoder's ``keep_full`` form: pooled and full-resolution outputs rounded
+  separately, the pool taken from the unrounded activation),
+* gradients are rounded at the same tensors on the way back (``_Round.backward``), plus the activation gradient
+  ``g = dy * act'(y)`` of a conv+activation kernel, which the HIP path stores before the data / filter gradient use it.
+
+Kink decisions then happen on (almost always) identical values on both sides, and the whole-step bf16 gates of the GPU
+suite drop from 5e-2 to a few 1e-3 (what remains: float32 summation order can move a value across a bf16 rounding
+boundary — a 2^-8 relative change of ~0.03 % of the elements — and the few places listed in `KNOWN_MISMATCHES`).
+The fusion plan below restates vfd_gan_amd/nn.py:run_fused and the model files; a fusion added there must be added here,
+or the tight gates fail (that is the point).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+from . import anogan as OA
+from . import ganomaly as OG
+from . import mygannet as OM
+from .spatiotempconv import SpatioTemporalConv
+
+KNOWN_MISMATCHES = (
+    "a tensor with several consumers (ganomaly's fake: L1 loss, encoder2, netD) sums its incoming gradients in float32 here "
+    "and rounds once; the HIP path stores each contribution in bf16 before they are added",
+    "BatchNorm statistics of a conv -> BatchNorm pair come from the float32 accumulators in the HIP conv epilogue and from "
+    "the rounded tensor here (relative difference of the variance ~1e-6)",
+)
+
+
+def rbf(t):
+    """Round a float32 tensor to the nearest bfloat16 (ties to even, like v_cvt_pk_bf16_f32), result in float32."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return rbf(x) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (rbf(g) if ctx.bwd else g), None, None
+
+
+def R(x):
+    """A tensor the HIP path stores in bf16 in both directions (value forward, its gradient backward)."""
+    return _Round.apply(x, True, True)
+
+
+def RF(x):
+    """Stored forward only (its gradient is consumed inside the kernel that produces it)."""
+    return _Round.apply(x, True, False)
+
+
+def RB(x):
+    """Stored backward only (the gradient w.r.t. a value that never leaves the registers forward)."""
+    return _Round.apply(x, False, True)
+
+
+def wq(w):
+    """The packed bf16 filter copy, straight-through to the float32 master parameter."""
+    return w + (rbf(w.detach()) - w.detach())
+
+
+_CONVS = (nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d, nn.ConvTranspose3d, nn.Linear)
+_BNS = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+_ACTS = (nn.ReLU, nn.LeakyReLU, nn.Sigmoid, nn.Tanh)
+
+
+def conv_q(m, x):
+    """The layer `m` with its bf16 filter copy; bias stays float32 (added to the float32 accumulator)."""
+    w = wq(m.weight)
+    if isinstance(m, nn.Linear):
+        return TF.linear(x, w, m.bias)
+    if isinstance(m, nn.ConvTranspose2d):
+        return TF.conv_transpose2d(x, w, m.bias, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    if isinstance(m, nn.ConvTranspose3d):
+        return TF.conv_transpose3d(x, w, m.bias, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    if isinstance(m, nn.Conv2d):
+        return TF.conv2d(x, w, m.bias, m.stride, m.padding, m.dilation, m.groups)
+    return TF.conv3d(x, w, m.bias, m.stride, m.padding, m.dilation, m.groups)
+
+
+def _triple(v):
+    return (v,) * 3 if isinstance(v, int) else tuple(v)
+
+
+def pool_fusable(pool, dhw):
+    """vfd_gan_amd.functional.pool_fusable: kernel == stride, every extent 1 or 2 (not all 1), no padding, input a multiple."""
+    k = _triple(pool.kernel_size)
+    s = _triple(pool.stride if pool.stride is not None else pool.kernel_size)
+    p = _triple(pool.padding)
+    return k == s and p == (0, 0, 0) and all(v in (1, 2) for v in k) and k != (1, 1, 1) and all(d % v == 0 for d, v in zip(dhw, k))
+
+
+def bn_act_pool(bn, act, x, pool=None, keep_full=False):
+    """BatchNorm(+activation)(+AvgPool3d) as ONE HIP pass: rounded after the last fused stage."""
+    y = bn(x)
+    if act is not None:
+        y = act(y)
+    if pool is None:
+        return R(y)
+    if keep_full:
+        return R(pool(y)), R(y)
+    return R(pool(y))
+
+
+def run_seq(mods, x, fused_tail_pool=True):
+    """vfd_gan_amd.nn.run_fused on a list of stock torch.nn layers, with the bf16 rounding points of the HIP kernels."""
+    mods = list(mods)
+    n, i = len(mods), 0
+
+    def is_conv(j):
+        return j < n and isinstance(mods[j], _CONVS) and not isinstance(mods[j], nn.Linear)
+
+    def run_bn(j, x, from_conv):
+        bn = mods[j]
+        act = mods[j + 1] if (j + 1 < n and isinstance(mods[j + 1], _ACTS)) else None
+        k = j + (2 if act is not None else 1)
+        if (from_conv and x.dim() == 5 and k < n and isinstance(mods[k], nn.AvgPool3d) and bn.training
+                and pool_fusable(mods[k], tuple(x.shape[2:]))):
+            return bn_act_pool(bn, act, x, mods[k]), k + 1
+        return bn_act_pool(bn, act, x), k
+
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        if isinstance(m, _CONVS):
+            if isinstance(nxt, _ACTS):
+                # conv + activation in one kernel.  Backward: g = dy * act'(y) is stored (RB); dy itself is stored by the
+                # consumer's data-gradient kernel unless that kernel applies act' in its own epilogue (the next conv of the
+                # same list claims it: nn.run_fused `claim_act_grad`)
+                claimed = not isinstance(m, nn.Linear) and is_conv(i + 2)
+                y = nxt(RB(conv_q(m, x)))
+                x = RF(y) if claimed else R(y)
+                i += 2
+                continue
+            x = R(conv_q(m, x))
+            if isinstance(nxt, _BNS) and not isinstance(m, nn.Linear):
+                x, i = run_bn(i + 1, x, True)
+                continue
+            i += 1
+            continue
+        if isinstance(m, _BNS):
+            x, i = run_bn(i, x, False)
+            continue
+        if isinstance(m, nn.Dropout):
+            x = R(m(x)) if (m.training and m.p > 0) else x
+        elif isinstance(m, (nn.AvgPool3d, nn.Upsample) + _ACTS):
+            x = R(m(x))
+        else:
+            raise NotImplementedError("bf16-faithful plan for %s" % type(m).__name__)
+        i += 1
+    return x
+
+
+# ---- the nets (the fusion structure of vfd_gan_amd/models/*.py) --------------------------------------------------------------
+def stconv(m, x):
+    """SpatioTemporalConv (vfd_gan_amd/models/spatiotempconv.py: run_fused over its four layers)."""
+    return run_seq([m.spatial_conv, m.bn, m.relu, m.temporal_conv], x)
+
+
+def conv_bn_act(block, x, pool=None, keep_full=False):
+    """models/mygannet.py:_conv_bn_act (NetgConv / NetdConv)."""
+    y = stconv(block.conv, x)
+    if pool is not None and pool_fusable(pool, tuple(y.shape[2:])) and block.bn.training:
+        return bn_act_pool(block.bn, block.lrelu, y, pool, keep_full)
+    y = bn_act_pool(block.bn, block.lrelu, y)
+    if pool is None:
+        return y
+    return (R(pool(y)), y) if keep_full else R(pool(y))
+
+
+def upsample_cat(up, x, skip):
+    """functional.upsample_cat: cat([Upsample(x), skip]) written by one pass (channel count of x a multiple of 8), else the
+    two-pass form (up-sampled tensor stored, then concatenated)."""
+    return R(torch.cat([up(x), skip], dim=1)) if x.shape[1] % 8 == 0 else torch.cat([R(up(x)), skip], dim=1)
+
+
+def _drop(m, x):
+    return R(m(x)) if (m.training and m.p > 0) else x
+
+
+def mygan_netg(g, x):
+    p1, d1 = conv_bn_act(g.dconv1, x, g.avgpool, True)
+    p2, d2 = conv_bn_act(g.dconv2, p1, g.avgpool, True)
+    p3, d3 = conv_bn_act(g.dconv3, p2, g.avgpool, True)
+    p4, d4 = conv_bn_act(g.dconv4, p3, g.avgpool, True)
+    latent = conv_bn_act(g.dconv5, p4)
+    x = _drop(g.dropout, conv_bn_act(g.uconv5, latent))
+    x = _drop(g.dropout, conv_bn_act(g.uconv4, upsample_cat(g.upsamp, x, d4)))
+    x = _drop(g.dropout, conv_bn_act(g.uconv3, upsample_cat(g.upsamp, x, d3)))
+    x = _drop(g.dropout, conv_bn_act(g.uconv2, upsample_cat(g.upsamp, x, d2)))
+    x = conv_bn_act(g.uconv1, upsample_cat(g.upsamp, x, d1))
+    return run_seq([g.conv_last, g.sigmoid], x)
+
+
+def _disc(d, x, convs):
+    for c in convs:
+        x = conv_bn_act(c, x, d.avgpool)
+    features = x
+    x = R(d.gpool(features))
+    cls = run_seq([d.linear, d.sigmoid], x.view(x.shape[0], -1))
+    return cls.squeeze(1), features
+
+
+def mygan_netd(d, x, y):
+    s = d.spatdisc
+    t = d.tempdisc
+    s_cls, s_feat = _disc(s, x, (s.dconv1, s.dconv2, s.dconv3, s.dconv4, s.dconv5, s.dconv6))
+    t_cls, t_feat = _disc(t, y, (t.dconv1, t.dconv2, t.dconv3))
+    return s_cls, s_feat, t_cls, t_feat
+
+
+def anogan_netg(g, z):
+    x = run_seq(g.layer1, z)
+    x = x.view(x.size()[0], *g.seed_shape)
+    return run_seq(g.layer3, run_seq(g.layer2, x))
+
+
+def anogan_netd(d, x):
+    x = run_seq(d.layer2, run_seq(d.layer1, x))
+    x = x.view(x.size()[0], -1)
+    return run_seq(d.fc, x), x
+
+
+def ganomaly_netd(d, x):
+    features = run_seq(d.features, x)
+    return run_seq(d.classifier, features).view(-1, 1).squeeze(1), features
+
+
+def ganomaly_netg(g, x):
+    latent_i = run_seq(g.encoder1.main, x)
+    gen = run_seq(g.decoder.main, latent_i)
+    return gen, latent_i, run_seq(g.encoder2.main, gen)
+
+
+_FORWARD = {OG.NetG: ganomaly_netg, OG.NetD: ganomaly_netd, OG.Encoder: lambda m, x: run_seq(m.main, x),
+            OG.Decoder: lambda m, x: run_seq(m.main, x), OA.NetG: anogan_netg, OA.NetD: anogan_netd,
+            OM.NetG: mygan_netg, OM.NetD: mygan_netd, SpatioTemporalConv: stconv, nn.Sequential: run_seq}
+
+
+class Faithful(nn.Module):
+    """``Faithful(net)(x)`` = the bf16-faithful forward of oracle net `net` (same parameters: the oracle's step functions,
+    optimisers and state_dict comparisons keep working on `net` itself).  Inputs are rounded at the entry (F.to_cl)."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+        self._fwd = _FORWARD[type(net)]
+
+    def forward(self, *xs):
+        return self._fwd(self.net, *[RF(x) for x in xs])

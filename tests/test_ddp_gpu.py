@@ -1,5 +1,6 @@
-"""GPU test of the data-parallel step logic: 2 ranks (gloo, both on cuda:0) stepping identical clips must reproduce
-the single-process run — eager (hook-driven bucketed reductions) and graph mode (phase graphs + reductions between)."""
+"""GPU test of the data-parallel step logic: 2 ranks (gloo, both on cuda:0), each stepping its OWN clips, must reproduce a
+one-process two-replica emulation of the same program (gradient arenas summed by hand, tests/ddp_worker.py "emulate2") —
+eager (hook-driven bucketed reductions) and graph mode (phase graphs + reductions between)."""
 import json
 import os
 import socket
@@ -35,8 +36,9 @@ def _run(mode, world, tmp_path, which="ganomaly", rccl_single=False):
 def test_two_ranks_match_single_process(which, mode, dev, tmp_path):
     """All three models: ganomaly / mygan (one backward per net and step), anogan (TWO backward passes into netD before
     its reduction: GradReducer.arm(passes=2)); graph mode runs the models' step_program() with asynchronous
-    reductions between the captured graphs."""
-    one = _run(mode, 1, tmp_path, which)
+    reductions between the captured graphs.  Ranks hold DIFFERENT clips (and noise): the expected values come from the
+    collective-free two-replica emulation, and the workers assert after every reduction that their gradient arenas are equal."""
+    one = _run("emulate2", 1, tmp_path, which)
     two = _run(mode, 2, tmp_path, which)
     assert two["world"] == 2
     for k, v in one["errors"].items():

@@ -137,6 +137,59 @@ def test_graph_replay_equals_eager(dev, tmp_path):
     assert int(b.optimizer_g._step_dev.item()) == 5
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_graph_replay_after_reinit_d(dt, dev, tmp_path):
+    """reference models/ganomaly.py:519: `err_d < 1e-5 -> reinit_d()` is a host decision between replays.  A replay runs no
+    Python, so reinit_d itself must refresh netD's packed filter copies (in place): force the branch once and require the
+    following replays to equal the eager run that takes the same branch (f32: bit for bit; bf16: float atomics in the
+    statistics, 1e-3)."""
+    from vfd_gan_amd.graph import GraphedStep
+    from vfd_gan_amd.lib.data import synthetic_batch
+    B, T, S = 2, 4, 32
+    a, _, _, _ = _build(tmp_path, dev, dt, B, T, S, 16)
+    b, _, _, _ = _build(tmp_path, dev, dt, B, T, S, 16)
+    batch = synthetic_batch(B, T, S, 3, seed=210)
+
+    def arm(m, at):
+        calls = [0]
+        real_reinit = m.reinit_d
+
+        def collapsed():
+            calls[0] += 1
+            return calls[0] == at
+
+        def reinit():
+            torch.manual_seed(4242)
+            torch.cuda.manual_seed(4242)      # the same re-initialised weights on both models
+            real_reinit()
+        m.d_collapsed, m.reinit_d = collapsed, reinit
+
+    # eager: 2 warm-up steps, then 3 steps with the collapse branch taken after the FIRST of them
+    a.set_input(batch)
+    for _ in range(2):
+        a.optimize_params(check_collapse=False)
+    arm(a, 1)
+    for _ in range(3):
+        a.optimize_params(check_collapse=True)
+    b.set_input(batch)
+    step = GraphedStep(b, warmup=2).capture()
+    arm(b, 1)
+    for _ in range(3):
+        step.replay()
+    ea, eb = a.errors(), b.errors()
+    for k in ea:
+        if dt == torch.float32:
+            assert ea[k] == eb[k], (k, ea[k], eb[k])
+        else:
+            assert abs(ea[k] - eb[k]) <= 1e-3 * max(abs(ea[k]), 1e-3), (k, ea[k], eb[k])
+    for net in ("netg", "netd"):
+        for (k, v), (_, r) in zip(getattr(a, net).state_dict().items(), getattr(b, net).state_dict().items()):
+            if dt == torch.float32:
+                assert torch.equal(v, r), (net, k)
+            elif v.dtype.is_floating_point:
+                assert relrms(v, r) < 2e-2, (net, k, relrms(v, r))      # (Adam turns last-bit gradient noise into +-lr moves)
+
+
 def _grad_errors(model, og, od):
     out = {}
     for (k, p), (_, r) in list(zip(model.netg.named_parameters(), og.named_parameters())) + \

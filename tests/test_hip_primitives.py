@@ -117,6 +117,39 @@ def test_conv_family(case, dt, dev):
     assert float(yc.t[..., yc.C:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("sub", [0, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("tr", [False, True], ids=["conv", "convT"])
+def test_conv_igemm_flexible_pixel_tile(tr, sub, dev):
+    """conv_igemm<bf16,256c x 256p> with a run-time pixel extent of 12..16 sub-tiles of 16 pixels (vfd_conv_set_tile_sub; 0 =
+    chosen per layer): k4 s2 (transposed: four output classes), 200 output channels (a partial channel tile), ragged pixel count
+    (several tiles, a partial last one), with bias + LeakyReLU + BatchNorm statistics in the epilogue: the same values
+    whatever the tile extent, and equal to torch's on the bf16-rounded operands."""
+    from vfd_gan_amd import _lib, functional as F
+    lib = _lib.load()
+    cin, cout = 40, 200
+    xs = (3, cin, 26, 22) if not tr else (3, cin, 13, 11)
+    x = _rand(xs, 11).bfloat16().float()
+    w = _rand(((cin, cout) if tr else (cout, cin)) + (4, 4), 12, 0.2).bfloat16().float()
+    b = _rand((cout,), 13, 0.5)
+    yr = TF.conv_transpose2d(x, w, b, 2, 1) if tr else TF.conv2d(x, w, b, 2, 1)
+    prev = lib.vfd_conv_set_tile_sub(sub)
+    try:
+        xc = F.to_cl(x.to(dev), torch.bfloat16)
+        stats = F.new_stats_buffer(cout, dev)
+        yc = F.conv(xc, torch.nn.Parameter(w.to(dev)), torch.nn.Parameter(b.to(dev)), 2, 1, 0, tr, _lib.ACT_LRELU, 0.2, stats)
+        name = F._conv_kernel_name(F._make_desc(3, (1,) + xs[2:], cin, (1,) + tuple(yr.shape[2:]), cout, (1, 4, 4), (1, 2, 2), (0, 1, 1), tr, torch.bfloat16))
+        torch.cuda.synchronize()
+    finally:
+        lib.vfd_conv_set_tile_sub(prev)
+    assert name == "conv_igemm<bf16,256c_x_256p>", name
+    want = TF.leaky_relu(yr, 0.2)
+    assert relerr(yc.to_torch(), want) < TOL[torch.bfloat16]
+    assert float(yc.t[..., cout:].abs().sum()) == 0.0
+    st = stats.view(F.STATS_REPLICAS, 2, F.cpad(cout)).sum(0).cpu()
+    yf = yr.permute(1, 0, 2, 3).reshape(cout, -1).double()
+    assert relerr(st[0, :cout], yf.sum(1).float()) < 1e-3 and relerr(st[1, :cout], (yf * yf).sum(1).float()) < 1e-3
+
+
 @pytest.mark.parametrize("dt", DTYPES, ids=["f32", "bf16"])
 def test_conv_fused_act_and_stats(dt, dev):
     from vfd_gan_amd import _lib, functional as F

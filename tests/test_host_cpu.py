@@ -266,3 +266,34 @@ def test_ring_kernels_isa_audit():
                     bad[r["name"]] = v
     assert rings >= 20, "the audit found only %d ring loops: parser out of step with the compiler's output" % rings
     assert not bad, bad
+
+
+def test_bench_gpus_n_launches_one_rank_per_gpu_itself(monkeypatch):
+    """`python bench.py --gpus 8 ...` with WORLD_SIZE unset must start the ranks itself: a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py <same flags>`, issued
+    before the parent has initialised the GPU, whose exit code becomes the parent's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+    assert not torch.cuda.is_initialized()
+    # under a launcher (WORLD_SIZE set) nothing is spawned: parse_args keeps the driver's flags
+    a = bench.parse_args(["--gpus", "2", "--steps", "3"])
+    assert a.gpus == 2 and a.steps == 3 and a.batch == 32 and a.isize == 112 and not a.explicit

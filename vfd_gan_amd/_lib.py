@@ -51,6 +51,7 @@ SIGNATURES = {
     "vfd_conv_workspace": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.POINTER(c_sz)]),
     "vfd_conv_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), c_int, ctypes.c_char_p, c_sz]),
     "vfd_conv_set_halo_mode": (c_int, [c_int]),
+    "vfd_conv_set_tile_sub": (c_int, [c_int]),
     "vfd_wgrad_workspace": (c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_int32),
                                     ctypes.POINTER(c_sz)]),
     "vfd_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_sz, c_vp]),

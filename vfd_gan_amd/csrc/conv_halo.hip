@@ -370,6 +370,14 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
       if (p.dims[i][r].nk < 1) return 0;           // a class without taps (k < s): leave it to the general kernel
   }
   const bool frames = Q0[0] == 1 && d->Di == 1;
+  if (frames) {
+    // the <.,1,16> tile is sized WITHOUT a depth halo (HaloCfg::HD_MAX == 1): a depth-1 input under a filter with depth taps
+    // (Conv3d(k=3, pad=1) on (N,C,1,H,W), or a class of a transposed form with 2-3 depth taps) would stage HD = 3 planes past
+    // HALO_BYTES into the filter ring.  Those shapes stay on conv_igemm.
+    const int nr = d->transposed ? s[0] : 1;
+    for (int r = 0; r < nr; ++r)
+      if (p.dims[0][r].nk != 1) return 0;
+  }
   if (!frames && Q0[0] < 3) return 0;              // 2-deep volumes would leave half of a 4-deep tile empty
   if (Q0[2] < 12 || Q0[1] < (frames ? 12 : 3)) return 0;
   const int TD = frames ? 1 : 4, TH = frames ? 16 : 4;
@@ -387,6 +395,16 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
   p.fgroup = make_fastdiv((uint32_t)(p.ncls * p.ny));
   p.fntw = make_fastdiv((uint32_t)p.ntw); p.fnth = make_fastdiv((uint32_t)p.nth); p.fntd = make_fastdiv((uint32_t)p.ntd);
   if (p.nwork >= 0x7fffffffLL) return 0;
+  {
+    // host-side bound of what the kernel stages: every class's halo block must fit the tile's compile-time halo region
+    const int hd_max = frames ? 1 : TD + 2, s_max = halo_pitch(hd_max * (TH + 2)), rows_max = 18 * s_max;
+    for (int rd = 0; rd < (d->transposed ? s[0] : 1); ++rd)
+      for (int rh = 0; rh < (d->transposed ? s[1] : 1); ++rh)
+        for (int rw = 0; rw < (d->transposed ? s[2] : 1); ++rw) {
+          const int HD = TD + p.dims[0][rd].nk - 1, HH = TH + p.dims[1][rh].nk - 1, HW = 16 + p.dims[2][rw].nk - 1;
+          VFD_REQUIRE(HD <= hd_max && HW * halo_pitch(HD * HH) <= rows_max, "conv_halo: halo block %dx%dx%d exceeds the tile's LDS region", HD, HH, HW);
+        }
+  }
   if (frames) return tile_c == 64 ? launch_halo<64, 1, 16>(p, st) : launch_halo<32, 1, 16>(p, st);
   return tile_c == 64 ? launch_halo<64, 4, 4>(p, st) : launch_halo<32, 4, 4>(p, st);
 }

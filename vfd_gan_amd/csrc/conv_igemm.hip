@@ -42,6 +42,7 @@ struct ConvP {
   float* ws;
   int variant;  // tuning: pipeline variant override (0 = default), env VFD_IGEMM_VARIANT
   int ny, ncls, mbp, xcd_order;   // channel tiles, output classes, pixel tiles rounded up to 8, workgroup order (see kernel)
+  int tile_sub;          // FLEX kernels: 16-pixel sub-tiles per pixel tile (<= WAVES_P * NJ), see conv_igemm_kernel
   int dim_tab;           // 1: dims[][] below is valid
   DimClass dims[3][DIM_TAB];   // [d,h,w][output class r]: built on the host (make_dim_host), so that a workgroup's setup
                                // is scalar loads instead of ~15 integer divisions (one of them 64-bit) per dimension
@@ -102,21 +103,32 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   // one 64-byte K sub-step = 32 bf16 = one v_mfma_f32_16x16x32_bf16 per 16x16 tile
-  template <int NI, int NJ, int KSUB>
+  // `last` (wave-uniform; FLEX tiles): whether the wave's last pixel sub-tile (j = NJ - 1) is in use.  Only that sub-tile's
+  // fragment read and MFMAs are predicated: ONE code path, no second copy of the loop body (the 16-wave tile sits at its
+  // 128-register cap: a duplicated body spilled 153 registers, tools/isa_audit.py).
+  template <int NI, int NJ, int KSUB, bool FLEX = false>
   __device__ static __forceinline__ void step(const char* wt, const char* pt, int wrow0, int prow0, int lane,
-                                              f32x4 (&acc)[NI][NJ]) {
+                                              f32x4 (&acc)[NI][NJ], bool last = true) {
     const int r = lane & 15, ch = lane >> 4;
+    constexpr int NJS = FLEX ? NJ - 1 : NJ;      // sub-tiles that are always in use
 #pragma unroll
     for (int ks = 0; ks < KSUB; ++ks) {
-      bf16x8 a[NI], b[NJ];
+      bf16x8 a[NI], b[NJS];
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wt + lds_off<KSUB>(wrow0 + i * 16 + r, ch + 4 * ks));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, ch + 4 * ks));
+      for (int j = 0; j < NJS; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, ch + 4 * ks));
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJS; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if constexpr (FLEX) {
+        if (last) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + (NJ - 1) * 16 + r, ch + 4 * ks));
+#pragma unroll
+          for (int i = 0; i < NI; ++i) acc[i][NJ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl, acc[i][NJ - 1], 0, 0, 0);
+        }
+      }
     }
   }
 };
@@ -179,8 +191,19 @@ __device__ uint4 g_zero_page[4];
 // ring, ONE raw s_barrier per K-step, counted vmcnt so that STAGES-2 future steps stay in flight across the barrier.
 // The LDS image is lane-linear per wave-instruction (row = lane/4, 16-byte slot = lane%4), so the bank swizzle of
 // lds_off() is applied to the SOURCE: slot s of row r is fed logical chunk s ^ sw(r).
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3 : ((STAGES * KSUB <= 3 && NI * NJ <= 16) ? 4 : 2))) void conv_igemm_kernel(const ConvP p) {
+//
+// FLEX (the 16-wave 256c x 256p tile): the pixel extent of a tile is a RUN-TIME number of 16-pixel sub-tiles,
+// p.tile_sub in [WAVES_P * (NJ - 1), WAVES_P * NJ], dealt to the WAVES_P pixel-waves as evenly as possible (a wave column
+// takes NJ or NJ - 1 of them; its unused sub-tile is never staged, never multiplied and is an out-of-range row to the
+// epilogue).  The four waves that share a SIMD are the four pixel-wave columns of one channel-wave row, so the SIMD's MFMA
+// work is tile_sub / (WAVES_P * NJ) of the full tile's.  Why: one workgroup per CU, and the pyramid layers have 196 / 392
+// full tiles (25088 = 98 x 256 pixels per class) = 77 % of 256 CUs in the last round; 13 sub-tiles (208 pixels) give
+// 242 / 484 tiles, i.e. the same number of rounds at 13/16 of the work per round (host: pick_tile_sub).
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false, bool FLEX = false>
+// launch bound = waves per SIMD the tile is DESIGNED for (a bound the allocator cannot meet only constrains it for nothing and
+// draws "failed to meet occupancy target"): 4-wave tiles with >= 32 accumulator registers hold 2 workgroups' worth of waves
+// per SIMD (their LDS allows 2-3 workgroups per CU, their 130-170 registers 2-3); the 16-channel tile reaches 3
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? (NI * NJ <= 4 ? 3 : 2) : ((STAGES * KSUB <= 3 && NI * NJ <= 16) ? 4 : 2))) void conv_igemm_kernel(const ConvP p) {
   constexpr int TILE_C = WAVES_C * NI * 16;
   constexpr int TILE_P = WAVES_P * NJ * 16;
   constexpr int VEC = Elem<T>::VEC;
@@ -197,6 +220,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   constexpr int DUMP_OFF = STAGES * STAGE_BYTES;   // 1 KiB sink for the padding DMAs of waves without a real row group
   static_assert(NWAVES == 4 || NWAVES == 8 || NWAVES == 16, "4, 8 or 16 waves per workgroup");
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  static_assert(!FLEX || (STAGES == 2 && std::is_same<T, bf16_t>::value && RPI <= 16 && NJ >= 2),
+                "FLEX skips the DMAs of unused sub-tiles: only where the ring wait is vmcnt(0) (2 stages)");
 
   constexpr int DUMP_BYTES = (NW % NWAVES == 0 && NP % NWAVES == 0) ? 0 : 1024;
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES + DUMP_BYTES];
@@ -236,8 +261,22 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   const DimClass dh = p.dim_tab ? p.dims[1][rh] : make_dim(p.transposed, rh, p.kh, p.sh, p.ph, p.Ho);
   const DimClass dw = p.dim_tab ? p.dims[2][rw] : make_dim(p.transposed, rw, p.kw, p.sw, p.pw, p.Wo);
   const long long Mcls = (long long)p.N * dd.Q * dh.Q * dw.Q;
-  const long long m0 = (long long)ptile * TILE_P;
+  // FLEX: pixel-wave column wp owns sub-tiles [wp*fq + min(wp, frem), +fq + (wp < frem)) of the tile's tsub
+  const int tsub = FLEX ? p.tile_sub : WAVES_P * NJ;
+  const int fq = tsub / WAVES_P, frem = tsub - fq * WAVES_P;
+  const long long m0 = (long long)ptile * (tsub * 16);
   if (m0 >= Mcls) return;  // uniform per workgroup
+  // tile row (the LDS / accumulator row: wave column, sub-tile, pixel) -> pixel index inside the class, or -1
+  auto row_m = [&](int r) -> long long {
+    if constexpr (!FLEX) {
+      return m0 + r;
+    } else {
+      const int wp = r / (NJ * 16), j = (r >> 4) % NJ;
+      if (j >= fq + (wp < frem ? 1 : 0)) return -1;
+      return m0 + ((wp * fq + min(wp, frem) + j) << 4) + (r & 15);
+    }
+  };
+  const int nj_w = FLEX ? fq + ((wave / WAVES_C) < frem ? 1 : 0) : NJ;     // sub-tiles of this wave (wave-uniform)
   const int n0 = ytile * TILE_C;
   const int ntaps = dd.nk * dh.nk * dw.nk;
   const int Kcls = ntaps * p.Cip;
@@ -278,11 +317,13 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   }
   // pixel rows of this thread
   int pn[NPT], pid[NPT], pih[NPT], piw[NPT];
+  bool pgroup[NPT];       // FLEX: this wave-instruction's rows belong to a sub-tile in use (wave-uniform)
 #pragma unroll
   for (int i = 0; i < NPT; ++i) {
     const int g = wave + NWAVES * i;
-    const long long m = m0 + g * RPI + lrow;
-    if (g < NP && m < Mcls) {
+    const long long m = row_m(g * RPI + lrow);
+    pgroup[i] = !FLEX || row_m(g * RPI) >= 0;
+    if (g < NP && m >= 0 && m < Mcls) {
       uint32_t q = (uint32_t)m, qw, qh, qd;     // M < 2^31 (checked on the host): multiply-shift divisions
       fdivmod(q, dw.fq, q, qw);
       fdivmod(q, dh.fq, q, qh);
@@ -329,6 +370,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int g = wave + NWAVES * i;
+      if (FLEX && !pgroup[i]) continue;      // rows of a sub-tile this tile does not use: nothing reads them
       const char* src = (ppix_off[i] != NONE) ? reinterpret_cast<const char*>(xg) + ((size_t)ppix_off[i] << 4) + kc * (int)sizeof(T) : zero;
       const uint32_t dst = (NP % NWAVES == 0 || g < NP) ? pt + g * 1024 : smem_base + DUMP_OFF;
       dma16_to_lds(src, dst);
@@ -382,7 +424,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
       advance_k();
       const char* wt = smem + stage * STAGE_BYTES;
       const char* pt = wt + TILE_C * ROWB;
-      Mma<T>::template step<NI, NJ, KSUB>(wt, pt, wave_c0, wave_p0, lane, acc);
+      if constexpr (FLEX) Mma<T>::template step<NI, NJ, KSUB, true>(wt, pt, wave_c0, wave_p0, lane, acc, nj_w == NJ);
+      else Mma<T>::template step<NI, NJ, KSUB>(wt, pt, wave_c0, wave_p0, lane, acc);
       if (++stage == STAGES) stage = 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the trailing zero-page DMAs before LDS is released
@@ -394,11 +437,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     float* slab = p.ws + (size_t)ksl * (size_t)Mcls * p.Cop;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const long long m = m0 + wave_p0 + j * 16 + (lane & 15);
+      const long long m = row_m(wave_p0 + j * 16 + (lane & 15));
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int c = n0 + wave_c0 + i * 16 + cq;
-        if (m < Mcls && c < p.Cop)
+        if (m >= 0 && m < Mcls && c < p.Cop)
           *reinterpret_cast<float4*>(slab + (size_t)m * p.Cop + c) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
@@ -412,8 +455,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
   e.oscale = 1.f;
   if constexpr (std::is_same<T, fp8_t>::value) e.oscale = 1.f / (p.qscale_x[0] * p.qscale_w[0]);
   auto out_offset = [&](int r) -> long long {       // tile row -> element offset of the output pixel, or -1
-    const long long m = m0 + r;
-    if (m >= Mcls) return -1;
+    const long long m = row_m(r);
+    if (m < 0 || m >= Mcls) return -1;
     uint32_t q = (uint32_t)m, qw, qh, qd;
     fdivmod(q, dw.fq, q, qw);
     fdivmod(q, dh.fq, q, qh);
@@ -422,7 +465,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? 3
     return ((((long long)(n * p.Do + (int)qd * dd.so + dd.r) * p.Ho + (int)qh * dh.so + dh.r) * p.Wo + (int)qw * dw.so + dw.r)) * p.Cop;
   };
   conv_epilogue<typename OutOf<T>::type, WAVES_C, WAVES_P, NI, NJ, STAGES * STAGE_BYTES + DUMP_BYTES, BN, std::is_same<T, fp8_t>::value>(smem, acc, e, n0, ptile + cls_id, out_offset,
-                                                                                [&](int r) { return m0 + r < Mcls; });
+                                                                                [&](int r) { const long long m = row_m(r); return m >= 0 && m < Mcls; });
 }
 
 // y[m][c] = act(sum_ks ws[ks][m][c] + bias[c]) for the split-K path (regular convolutions only: out pixel == m)
@@ -462,10 +505,36 @@ int pick_ksplit(const ConvP& p, long long M, int bk) {
   return ks < 2 ? 1 : (int)ks;
 }
 
-template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false>
+// FLEX tiles (one workgroup per CU): the number of 16-pixel sub-tiles per pixel tile, in [lo, hi], that minimises
+// rounds x (work per round): rounds = ceil(tiles / CUs) — workgroups of one launch are equal, so a launch takes whole rounds —
+// and a tile costs its sub-tiles plus a fixed part (prologue, epilogue set-up: ~2 sub-tiles' worth).
+int g_tile_sub_forced = -1;     // -1: not yet read from the environment (VFD_IGEMM_TILE_SUB); see vfd_conv_set_tile_sub
+static int pick_tile_sub(long long maxM, int ny, int ncls, int lo, int hi) {
+  if (g_tile_sub_forced < 0) g_tile_sub_forced = getenv("VFD_IGEMM_TILE_SUB") ? atoi(getenv("VFD_IGEMM_TILE_SUB")) : 0;
+  const int forced = g_tile_sub_forced;
+  if (forced >= lo && forced <= hi) return forced;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  int best = hi;
+  long long best_cost = -1;
+  for (int n = hi; n >= lo; --n) {
+    const long long tiles = ((maxM + 16LL * n - 1) / (16LL * n)) * ny * ncls;
+    const long long cost = ((tiles + cus - 1) / cus) * (n + 2);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = n; }
+  }
+  return best;
+}
+
+template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int STAGES, int KSUB, bool BN = false, bool FLEX = false>
 int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   constexpr int TILE_C = WAVES_C * NI * 16;
-  constexpr int TILE_P = WAVES_P * NJ * 16;
+  constexpr int TILE_P_FULL = WAVES_P * NJ * 16;
+  const int tile_sub = FLEX ? pick_tile_sub(maxM, (p.Cout + TILE_C - 1) / TILE_C, ncls, WAVES_P * (NJ - 1), WAVES_P * NJ) : WAVES_P * NJ;
+  const int TILE_P = tile_sub * 16;
   const long long mb = (maxM + TILE_P - 1) / TILE_P;
   if (mb <= 0) return VFD_OK;
   if (maxM >= 0x7fffffffLL) { vfd_set_error("conv: %lld output pixels per class exceed 2^31", maxM); return VFD_EINVAL; }
@@ -479,7 +548,12 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
     }
   }
   ConvP q = p;
-  q.ksplit = (p.mul.src != nullptr || std::is_same<T, fp8_t>::value) ? 1 : pick_ksplit<TILE_C, TILE_P>(p, maxM, 4 * KSUB * Elem<T>::VEC);
+  q.ksplit = (p.mul.src != nullptr || std::is_same<T, fp8_t>::value) ? 1 : pick_ksplit<TILE_C, TILE_P_FULL>(p, maxM, 4 * KSUB * Elem<T>::VEC);
+  q.tile_sub = tile_sub;
+  if constexpr (FLEX) {
+    // (few-pixel layers that split K keep the full tile: the slab layout is indexed by the full tile)
+    if (q.ksplit > 1 && tile_sub != WAVES_P * NJ) return launch_cfg<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB, BN, false>(p, maxM, ncls, st, ws_bytes, ws_query);
+  }
   const size_t need = q.ksplit > 1 ? (size_t)q.ksplit * (size_t)maxM * p.Cop * sizeof(float) : 0;
   if (ws_query != nullptr) { *ws_query = need; return VFD_OK; }
   if (q.ksplit > 1 && (p.ws == nullptr || ws_bytes < need)) q.ksplit = 1;   // no workspace: plain path
@@ -491,7 +565,7 @@ int launch_cfg(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t 
   const long long nwg = (long long)q.mbp * q.ny * ncls;
   if (nwg >= 0x7fffffffLL || q.ksplit > 65535) { vfd_set_error("conv: grid too large"); return VFD_EINVAL; }
   dim3 grid((unsigned)nwg, 1, (unsigned)q.ksplit);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB, BN>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, WAVES_C, WAVES_P, NI, NJ, STAGES, KSUB, BN, FLEX>), grid, dim3(64 * WAVES_C * WAVES_P), 0, st, q);
   VFD_CHECK_LAUNCH("conv_igemm");
   if (q.ksplit > 1) {
     const long long total = maxM * (p.Cop >> 3);
@@ -516,7 +590,7 @@ template <typename T>
 int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_bytes, size_t* ws_query) {
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (p.mul.bn_mean != nullptr) {      // BatchNorm hand-over: the default tile of each channel range, in its BN variant
-      if (p.Cout > 128) return launch_cfg<T, 4, 4, 4, 4, 2, 2, true>(p, maxM, ncls, st, ws_bytes, ws_query);
+      if (p.Cout > 128) return launch_cfg<T, 4, 4, 4, 4, 2, 2, true, true>(p, maxM, ncls, st, ws_bytes, ws_query);
       if (p.Cout > 64) return launch_cfg<T, 2, 4, 4, 4, 3, 1, true>(p, maxM, ncls, st, ws_bytes, ws_query);
       if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4, 3, 1, true>(p, maxM, ncls, st, ws_bytes, ws_query);
       vfd_set_error("conv: the BatchNorm hand-over needs more than 32 output channels");
@@ -536,7 +610,8 @@ int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_b
     if (variant == 4 || variant == 17) return launch_cfg<T, 4, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 256c x 128p, 8 waves
     // 256c x 256p, 16 waves (one workgroup per CU), 128-byte rows, 2 stages: the only tile whose DMA bytes per MFMA
     // cycle (31 B/clk/CU at full MFMA rate) fit under the 54 B/clk/CU the global->LDS path delivers with 128-byte rows
-    return launch_cfg<T, 4, 4, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);
+    if constexpr (std::is_same<T, bf16_t>::value) return launch_cfg<T, 4, 4, 4, 4, 2, 2, false, true>(p, maxM, ncls, st, ws_bytes, ws_query);
+    else return launch_cfg<T, 4, 4, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);
   }
   if (p.Cout > 32) return launch_cfg<T, 1, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  64 ch x 256 px
   if (p.Cout > 16) return launch_cfg<T, 1, 4, 2, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   //  32 ch x 256 px
@@ -646,6 +721,12 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   hipStream_t st = as_stream(stream);
   if (fp8) return launch_fp8(p, maxM, ncls, st, ws_bytes, ws_query);
   return d->dtype == VFD_BF16 ? launch<bf16_t>(p, maxM, ncls, st, ws_bytes, ws_query) : launch<float>(p, maxM, ncls, st, ws_bytes, ws_query);
+}
+
+extern "C" int vfd_conv_set_tile_sub(int sub) {
+  const int prev = g_tile_sub_forced < 0 ? (getenv("VFD_IGEMM_TILE_SUB") ? atoi(getenv("VFD_IGEMM_TILE_SUB")) : 0) : g_tile_sub_forced;
+  g_tile_sub_forced = sub < 0 ? 0 : sub;
+  return prev;
 }
 
 extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, char* buf, size_t n) {

@@ -317,6 +317,11 @@ class Ganomaly(GANBaseModel):
         self.netd.apply(weights_init_dcgan)
         vdist.broadcast_module(self.netd)
         F.invalidate_weight_cache()
+        # A hipGraph replay runs no Python: the packed (K-major, compute-dtype) copies the captured kernels read are refreshed
+        # only by the captured repack launch after each Adam step.  Re-pack netD's copies NOW, in place, or the next replay's
+        # netD forward / backward would read the pre-reinit filters next to the re-initialised BatchNorm weights.
+        self.optimizer_d._epoch[0] += 1
+        F.repack_owned(self.optimizer_d._epoch)
         if self.rank == 0:
             print('   Reloading net d')
 
