@@ -298,6 +298,20 @@ int vfd_avgpool_backward(int dtype, const void* dy, void* dx, int N, int D, int 
 int vfd_upsample2x_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, void* stream);
 int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C,
                             void* stream);
+/* nn.Upsample(scale_factor=(fd,fh,fw), mode='trilinear', align_corners=True), every factor 1 or 2: models/xception.py:84 uses
+ * (1,2,2); (2,2,2) is vfd_upsample2x_*.  y [N][fd D][fh H][fw W][CPAD(C)]. */
+int vfd_upsample_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, int fd, int fh, int fw, void* stream);
+int vfd_upsample_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C, int fd, int fh, int fw, void* stream);
+/* nn.MaxPool3d(kernel, stride, padding) (models/xception.py:57: (1,3,3), (1,s,s), (0,1,1)); floor mode, <= 255 taps, torch's
+ * first-maximum rule.  y and idx are [N][Do][Ho][Wo][CPAD(C)] (idx: uint8, the window-local index of each maximum, which the
+ * backward — a deterministic gather — reads instead of recomputing the windows). */
+int vfd_maxpool_forward(int dtype, const void* x, void* y, void* idx, int N, int D, int H, int W, int C, int kd, int kh, int kw,
+                        int sd, int sh, int sw, int pd, int ph, int pw, void* stream);
+int vfd_maxpool_backward(int dtype, const void* dy, const void* idx, void* dx, int N, int D, int H, int W, int C, int kd, int kh,
+                         int kw, int sd, int sh, int sw, int pd, int ph, int pw, void* stream);
+/* y = a + b (+ c when non-null), n elements (a multiple of 8), summed in float32 and rounded once: the residual join
+ * `x += skip` of models/xception.py:68, and the sum of the gradients returning to a tensor with several consumers. */
+int vfd_add(int dtype, const void* a, const void* b, const void* c, void* y, int64_t n, void* stream);
 /* torch.cat([Upsample(x), skip], dim=1) in one pass (U-Net decoder joint, models/mygannet.py:78-94): x [N][D][H][W][Ca]
  * (Ca a multiple of 8), skip [N][2D][2H][2W][CPAD(Cb)], y [N][2D][2H][2W][Ca + CPAD(Cb)]; the up-sampled tensor is never
  * materialised.  Backward: dx from the first Ca channels of dcat read in place, dskip = the remaining channels.     */

@@ -15,6 +15,10 @@ exactly the tensors the HIP path stores — and nowhere else:
 * BatchNorm -> activation (-> AvgPool3d where vfd_gan_amd.nn.run_fused / models.mygannet._conv_bn_act fuse it) is rounded
   once, after the last fused stage (the U-Net encoder's ``keep_full`` form: pooled and full-resolution outputs rounded
   separately, the pool taken from the unrounded activation),
+* the batch statistics of a conv -> BatchNorm pair are those of the conv's float32 accumulators (the HIP conv epilogue sums
+  them BEFORE the output is rounded; `bn_from`), applied to the rounded tensor.  Measured: with the statistics of the
+  rounded tensor instead, ~1.5 % of a layer's outputs land on the other side of a bf16 rounding boundary (the means differ by
+  the average rounding error, ~5e-6 sigma), the next layers amplify that, and four stages on a third of all elements differ,
 * gradients are rounded at the same tensors on the way back (``_Round.backward``), plus the activation gradient
   ``g = dy * act'(y)`` of a conv+activation kernel, which the HIP path stores before the data / filter gradient use it.
 
@@ -36,8 +40,8 @@ from .spatiotempconv import SpatioTemporalConv
 KNOWN_MISMATCHES = (
     "a tensor with several consumers (ganomaly's fake: L1 loss, encoder2, netD) sums its incoming gradients in float32 here "
     "and rounds once; the HIP path stores each contribution in bf16 before they are added",
-    "BatchNorm statistics of a conv -> BatchNorm pair come from the float32 accumulators in the HIP conv epilogue and from "
-    "the rounded tensor here (relative difference of the variance ~1e-6)",
+    "float32 summation order (MFMA K order, atomics) differs from torch's: a value within ~1e-6 relative of a bf16 rounding "
+    "boundary may round the other way (~0.001 % of a conv's outputs)",
 )
 
 
@@ -108,9 +112,58 @@ def pool_fusable(pool, dhw):
     return k == s and p == (0, 0, 0) and all(v in (1, 2) for v in k) and k != (1, 1, 1) and all(d % v == 0 for d, v in zip(dhw, k))
 
 
-def bn_act_pool(bn, act, x, pool=None, keep_full=False):
-    """BatchNorm(+activation)(+AvgPool3d) as ONE HIP pass: rounded after the last fused stage."""
-    y = bn(x)
+class _BnFrom(torch.autograd.Function):
+    """y = x * E + F, E = gamma * rstd, F = beta - mean * E with GIVEN batch statistics (those of the producing conv's float32
+    accumulators), and the backward of csrc/bn.hip: dx = E * (g - mean(g) - xh * mean(g * xh)), xh = (x - mean) * rstd taken from
+    the stored (rounded) x and the saved statistics."""
+
+    @staticmethod
+    def forward(ctx, x, mean, rstd, gamma, beta):
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        E = (gamma * rstd) if gamma is not None else rstd
+        Fc = (beta if beta is not None else 0.0) - mean * E
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.has = (gamma is not None, beta is not None)
+        return x * E.view(shape) + Fc.view(shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        dims = [0] + list(range(2, x.dim()))
+        xh = (x - mean.view(shape)) * rstd.view(shape)
+        n = x.numel() // x.shape[1]
+        sg = g.sum(dims)
+        sgx = (g * xh).sum(dims)
+        E = (gamma * rstd) if gamma is not None else rstd
+        dx = E.view(shape) * (g - (sg / n).view(shape) - xh * (sgx / n).view(shape))
+        return dx, None, None, (sgx if ctx.has[0] else None), (sg if ctx.has[1] else None)
+
+
+def bn_from(bn, x, t):
+    """Training-mode BatchNorm of the stored tensor `x` with the batch statistics of `t` (the producing conv's output BEFORE it
+    was rounded: the HIP conv epilogue adds up its float32 accumulators); running statistics updated like torch's."""
+    if t is None or not bn.training:
+        return bn(x)
+    dims = [0] + list(range(2, t.dim()))
+    n = t.numel() // t.shape[1]
+    td = t.detach().double()
+    mean = td.mean(dims)
+    var = (td * td).mean(dims) - mean * mean          # the fold of csrc/bn.hip (sum, sum of squares; in double)
+    rstd = (1.0 / torch.sqrt(var + bn.eps)).float()
+    if bn.track_running_stats:
+        with torch.no_grad():
+            m = bn.momentum
+            bn.running_mean.mul_(1 - m).add_(m * mean.float())
+            bn.running_var.mul_(1 - m).add_(m * (var * n / max(n - 1, 1)).float())
+            bn.num_batches_tracked += 1
+    return _BnFrom.apply(x, mean.float(), rstd, bn.weight, bn.bias)
+
+
+def bn_act_pool(bn, act, x, pool=None, keep_full=False, t=None):
+    """BatchNorm(+activation)(+AvgPool3d) as ONE HIP pass: rounded after the last fused stage.  `t`: the unrounded output of
+    the conv that produced x, when its epilogue supplied the statistics."""
+    y = bn_from(bn, x, t)
     if act is not None:
         y = act(y)
     if pool is None:
@@ -120,22 +173,25 @@ def bn_act_pool(bn, act, x, pool=None, keep_full=False):
     return R(pool(y))
 
 
-def run_seq(mods, x, fused_tail_pool=True):
-    """vfd_gan_amd.nn.run_fused on a list of stock torch.nn layers, with the bf16 rounding points of the HIP kernels."""
+def run_seq(mods, x, return_last_t=False):
+    """vfd_gan_amd.nn.run_fused on a list of stock torch.nn layers, with the bf16 rounding points of the HIP kernels.
+    return_last_t: also return the last layer's (a conv's) output before rounding (`last_stats` of run_fused: the caller
+    applies the BatchNorm that follows)."""
     mods = list(mods)
     n, i = len(mods), 0
+    last_t = None
 
     def is_conv(j):
         return j < n and isinstance(mods[j], _CONVS) and not isinstance(mods[j], nn.Linear)
 
-    def run_bn(j, x, from_conv):
+    def run_bn(j, x, t):
         bn = mods[j]
         act = mods[j + 1] if (j + 1 < n and isinstance(mods[j + 1], _ACTS)) else None
         k = j + (2 if act is not None else 1)
-        if (from_conv and x.dim() == 5 and k < n and isinstance(mods[k], nn.AvgPool3d) and bn.training
+        if (t is not None and x.dim() == 5 and k < n and isinstance(mods[k], nn.AvgPool3d) and bn.training
                 and pool_fusable(mods[k], tuple(x.shape[2:]))):
-            return bn_act_pool(bn, act, x, mods[k]), k + 1
-        return bn_act_pool(bn, act, x), k
+            return bn_act_pool(bn, act, x, mods[k], t=t), k + 1
+        return bn_act_pool(bn, act, x, t=t), k
 
     while i < n:
         m = mods[i]
@@ -150,14 +206,17 @@ def run_seq(mods, x, fused_tail_pool=True):
                 x = RF(y) if claimed else R(y)
                 i += 2
                 continue
-            x = R(conv_q(m, x))
-            if isinstance(nxt, _BNS) and not isinstance(m, nn.Linear):
-                x, i = run_bn(i + 1, x, True)
+            t = conv_q(m, x)
+            x = R(t)
+            if isinstance(nxt, _BNS) and not isinstance(m, nn.Linear) and nxt.training:
+                x, i = run_bn(i + 1, x, t)
                 continue
+            if i == n - 1:
+                last_t = t
             i += 1
             continue
         if isinstance(m, _BNS):
-            x, i = run_bn(i, x, False)
+            x, i = run_bn(i, x, None)
             continue
         if isinstance(m, nn.Dropout):
             x = R(m(x)) if (m.training and m.p > 0) else x
@@ -166,21 +225,21 @@ def run_seq(mods, x, fused_tail_pool=True):
         else:
             raise NotImplementedError("bf16-faithful plan for %s" % type(m).__name__)
         i += 1
-    return x
+    return (x, last_t) if return_last_t else x
 
 
 # ---- the nets (the fusion structure of vfd_gan_amd/models/*.py) --------------------------------------------------------------
-def stconv(m, x):
+def stconv(m, x, return_last_t=False):
     """SpatioTemporalConv (vfd_gan_amd/models/spatiotempconv.py: run_fused over its four layers)."""
-    return run_seq([m.spatial_conv, m.bn, m.relu, m.temporal_conv], x)
+    return run_seq([m.spatial_conv, m.bn, m.relu, m.temporal_conv], x, return_last_t)
 
 
 def conv_bn_act(block, x, pool=None, keep_full=False):
-    """models/mygannet.py:_conv_bn_act (NetgConv / NetdConv)."""
-    y = stconv(block.conv, x)
+    """models/mygannet.py:_conv_bn_act (NetgConv / NetdConv): the temporal conv's epilogue supplies the BatchNorm statistics."""
+    y, t = stconv(block.conv, x, True)
     if pool is not None and pool_fusable(pool, tuple(y.shape[2:])) and block.bn.training:
-        return bn_act_pool(block.bn, block.lrelu, y, pool, keep_full)
-    y = bn_act_pool(block.bn, block.lrelu, y)
+        return bn_act_pool(block.bn, block.lrelu, y, pool, keep_full, t=t)
+    y = bn_act_pool(block.bn, block.lrelu, y, t=t)
     if pool is None:
         return y
     return (R(pool(y)), y) if keep_full else R(pool(y))

@@ -238,6 +238,30 @@ def mygan224():
     OUT_JSON["mygan224"] = {"seeds": {"g": 61, "inp": 68}, "predict": summarize(out)}
 
 
+def baselines():
+    """the supervised baselines' nets (reference models/mystcnn.py AutoEncoder, models/xception.py Xception) at the
+    reference's 16x128x128, B=1, Dropout p=0, training-mode BatchNorm: forward, and ONE step of lib/train_stcnn.py:103-108
+    (BCELoss against the mask, Adam(2e-5, (0.5, 0.999))) restated by vfd_oracle.mystcnn.step around the reference's modules."""
+    import models.mystcnn as RMS
+    import models.xception as RX
+    from vfd_oracle import mystcnn as OMS
+    rec = {}
+    inp = seeded_tensor((1, 3, 16, 128, 128), 73)
+    gt = (seeded_tensor((1, 1, 16, 128, 128), 74, 0.0, 1.0) > 0.97).float()
+    for name, cls, seed in (("autoencoder", RMS.AutoEncoder, 71), ("xception", RX.Xception, 72)):
+        m = fill_module(cls(), seed).train()
+        set_dropout_p(m, 0.0)
+        opt = OMS.make_optimizer(m)
+        errs, predict = OMS.step(m, opt, inp, gt)
+        sd = sd_summary(m)
+        keys = list(m.state_dict().keys())
+        pick = [k for k in keys if k.endswith(("running_mean", "running_var"))][:4] + [k for k in keys if k.endswith("weight")][:3] + \
+               [k for k in keys if k.endswith("weight")][-3:]
+        rec[name] = {"seeds": {"net": seed, "inp": 73, "gt": 74}, "keys": keys, "n_params": sum(p.numel() for p in m.parameters()),
+                     "step_p0": {"errs": errs, "predict": summarize(predict)}, "after1": {k: sd[k] for k in pick}}
+    OUT_JSON["baselines"] = rec
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["kats", "args_defaults", "spatiotemp", "ganomaly", "anogan", "mygan"]
     jp, npz = os.path.join(HERE, "reference_vectors.json"), os.path.join(HERE, "reference_vectors.npz")

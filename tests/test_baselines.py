@@ -1,0 +1,127 @@
+"""GPU parity of the supervised baselines: reference models/mystcnn.py AutoEncoder and models/xception.py
+Xception on the HIP kernels, one training step of lib/train_stcnn.py:103-108 through VFD_STCNN.optimize_params at the
+reference's 16x128x128 against the vectors of the reference's own classes; the kernels new to this round (MaxPool3d, (1,2,2)
+up-sampling, residual add, gradient fan-out) against torch; `--ae` (MyGAN with the auto-encoder as its generator)."""
+import types
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from golden_util import check_errs, check_summary, load_golden
+from util import TOL, relerr, relrms
+
+pytestmark = pytest.mark.gpu
+JS, NPZ = load_golden()
+
+
+def _args(tmp, model, B, T, S, **kw):
+    d = dict(batchsize=B, nfr=T, isize=S, ich=3, lr=2e-5, beta1=0.5, w_adv=1, w_con=10, pos_weight=2, freq=10 ** 9, ep=1,
+             model=model, result_root=str(tmp), gpu=[0], ae=False, resume="", steps_per_epoch=1)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def _p0(m):
+    for mm in m.modules():
+        if isinstance(mm, torch.nn.Dropout):
+            mm.p = 0.0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", ["autoencoder", "xception"])
+def test_baseline_step_reference_geometry_golden(name, dt, dev, tmp_path):
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.lib.train_stcnn import VFD_STCNN
+    from vfd_oracle.weights import fill_module, seeded_tensor
+    R = JS["baselines"][name]
+    F.set_compute_dtype(dt)
+    tr = VFD_STCNN(_args(tmp_path, {"autoencoder": "c2plus1d", "xception": "xception"}[name], 1, 16, 128), None)
+    assert list(tr.model.state_dict().keys()) == R["keys"]
+    fill_module(tr.model, R["seeds"]["net"])
+    _p0(tr.model)
+    F.invalidate_weight_cache()
+    inp = seeded_tensor((1, 3, 16, 128, 128), R["seeds"]["inp"])
+    gt = (seeded_tensor((1, 1, 16, 128, 128), R["seeds"]["gt"], 0.0, 1.0) > 0.97).float()
+    tr.set_input((inp, inp, gt, torch.ones(1, 16)))
+    tr.optimize_params()
+    f32 = dt == torch.float32
+    check_errs({"err": tr.errors()["loss/err/train"]}, R["step_p0"]["errs"], 1e-4 if f32 else 3e-2, name)
+    if f32:
+        check_summary(tr.predict.to_torch(), R["step_p0"]["predict"], 1e-3, name + " predict")
+        sd = tr.model.state_dict()
+        for k, ref in R["after1"].items():
+            if "running" in k:
+                check_summary(sd[k].float(), ref, 2e-3, k)
+    F.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_maxpool_upsample122_add_fanout(dt, dev):
+    from vfd_gan_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(2, 13, 3, 9, 11, generator=g) * 2 - 1)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()          # bf16 values tie often: exercises the first-maximum rule
+    tol = TOL[dt]
+    # MaxPool3d((1,3,3), (1,2,2), (0,1,1)) as in models/xception.py:57, and a 3-D window with padding
+    for k, s, p in (((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((2, 2, 2), (2, 2, 2), (0, 0, 0))):
+        xr = x.clone().requires_grad_()
+        yr = TF.max_pool3d(xr, k, s, p)
+        gy = torch.rand(yr.shape, generator=g)
+        yr.backward(gy)
+        xd = x.to(dev).requires_grad_()
+        y = F.max_pool(F.to_cl(xd, dt), k, s, p).to_torch()
+        y.backward(gy.to(dev))
+        assert tuple(y.shape) == tuple(yr.shape) and relerr(y, yr) < 1e-6, (k, relerr(y, yr))
+        assert relerr(xd.grad, xr.grad) < tol, (k, relerr(xd.grad, xr.grad))
+    # Upsample(scale_factor=(1,2,2), trilinear, align_corners=True)
+    for f in ((1, 2, 2), (2, 1, 2), (2, 2, 2)):
+        xr = x.clone().requires_grad_()
+        yr = TF.interpolate(xr, scale_factor=tuple(float(v) for v in f), mode="trilinear", align_corners=True)
+        gy = torch.rand(yr.shape, generator=g)
+        yr.backward(gy)
+        xd = x.to(dev).requires_grad_()
+        y = F.upsample_trilinear(F.to_cl(xd, dt), f).to_torch()
+        y.backward(gy.to(dev))
+        assert tuple(y.shape) == tuple(yr.shape) and relerr(y, yr) < tol and relerr(xd.grad, xr.grad) < tol, (f, relerr(y, yr), relerr(xd.grad, xr.grad))
+    # residual add, and three consumers of one tensor through fanout: gradients summed in one float32 pass
+    a, b = x.to(dev).requires_grad_(), (x * 0.5 + 0.1).to(dev).requires_grad_()
+    y = F.add(F.to_cl(a, dt), F.to_cl(b, dt)).to_torch()
+    y.backward(torch.ones_like(y))
+    assert relerr(y, x + (x * 0.5 + 0.1)) < tol and relerr(a.grad, torch.ones_like(x)) < 1e-6 and relerr(b.grad, torch.ones_like(x)) < 1e-6
+    c = x.to(dev).requires_grad_()
+    h1, h2, h3 = F.fanout(F.to_cl(c, dt), 3)
+    (h1.to_torch() * 1.0 + h2.to_torch() * 2.0 + h3.to_torch() * 4.0).sum().backward()
+    assert relerr(c.grad, torch.full_like(x, 7.0)) < tol
+
+
+def test_mygan_with_autoencoder_generator(dev, tmp_path):
+    """--ae: MyGAN with models/mystcnn.py's AutoEncoder as netG (what reference models/mygannet.py:224-227 intends and cannot
+    run): one optimize_params at 16x64x64 against the oracle's step with the oracle's AutoEncoder, float32."""
+    from vfd_gan_amd import functional as F
+    from vfd_gan_amd.models import mygannet as HM
+    from vfd_oracle import mygannet as OM, mystcnn as OMS
+    from vfd_oracle.weights import fill_module, seeded_tensor
+    F.set_compute_dtype(torch.float32)
+    B, T, S = 1, 16, 64
+    og, od = fill_module(OMS.AutoEncoder(), 3).train(), fill_module(OM.NetD(OM.make_args(T, S)), 4).train()
+    _p0(og)
+    model = HM.MyGAN(_args(tmp_path, "mygan", B, T, S, ae=True), None)
+    assert type(model.netg).__name__ == "AutoEncoder"
+    model.netg.load_state_dict(og.state_dict())
+    model.netd.load_state_dict(od.state_dict())
+    _p0(model.netg)
+    F.invalidate_weight_cache()
+    inp = seeded_tensor((B, 3, T, S, S), 30)
+    gt = (seeded_tensor((B, 1, T, S, S), 40, 0.0, 1.0) > 0.97).float()
+    gf, pf = seeded_tensor((B, 3, T, S, S), 50), seeded_tensor((B, 3, T, S, S), 60)
+    ref, pred_ref = OM.step(og, od, *OM.make_optimizers(og, od), inp, gt, gf, pf)
+    model.set_input((inp, inp, gt, torch.ones(B, T)), gt_flow=gf, pre_flow=pf)
+    model.optimize_params()
+    got = model.errors()
+    for k, v in ref.items():
+        g = got["%s/%s/train" % (k[4], k)]
+        assert abs(g - v) <= 1e-4 * max(abs(v), 1e-3), (k, g, v)
+    assert relerr(model.predict.to_torch(), pred_ref) < 5e-4
+    F.set_compute_dtype(torch.bfloat16)

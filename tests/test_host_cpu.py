@@ -90,10 +90,10 @@ def test_args_match_reference_defaults():
 
 def test_trainer_rejects_unknown_model(capsys):
     from vfd_gan_amd import trainer
-    args = types.SimpleNamespace(model="c2plus1d", batchsize=1, nfr=4, isize=32, ich=3, steps_per_epoch=1)
+    args = types.SimpleNamespace(model="clstm", batchsize=1, nfr=4, isize=32, ich=3, steps_per_epoch=1)      # (the ConvLSTM baseline is not built)
     with pytest.raises(SystemExit):
         trainer.main(args)
-    assert "c2plus1d is None" in capsys.readouterr().out
+    assert "clstm is None" in capsys.readouterr().out
 
 
 def test_state_dict_keys_match_reference():
@@ -108,6 +108,14 @@ def test_state_dict_keys_match_reference():
     assert list(HM.NetD(HM.make_args()).state_dict().keys()) == JS["mygan"]["keys_d"]
     assert sum(p.numel() for p in HM.NetG().parameters()) == JS["mygan"]["n_params_g"]
     assert list(SpatioTemporalConv(3, 8, 3, padding=1).state_dict().keys()) == JS["spatiotemp"]["keys"]
+    # the supervised baselines: reference models/mystcnn.py, models/xception.py
+    from vfd_gan_amd.models.mystcnn import AutoEncoder
+    from vfd_gan_amd.models.xception import Xception
+    assert list(AutoEncoder().state_dict().keys()) == JS["baselines"]["autoencoder"]["keys"]
+    ae, xc = AutoEncoder(), Xception()
+    assert sum(p.numel() for p in ae.parameters()) == JS["baselines"]["autoencoder"]["n_params"]
+    assert list(xc.state_dict().keys()) == JS["baselines"]["xception"]["keys"]
+    assert sum(p.numel() for p in xc.parameters()) == JS["baselines"]["xception"]["n_params"]
     for key, m in JS["spatiotemp_intermed"].items():
         i, o, k = key.split(",", 2)
         assert SpatioTemporalConv(int(i), int(o), eval(k)).spatial_conv.out_channels == m

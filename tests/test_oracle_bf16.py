@@ -51,7 +51,8 @@ def test_ganomaly_faithful_step_is_float32_step_up_to_bf16_rounding():
 
 def test_fusion_plan_rounding_points():
     """run_seq rounds once per fused HIP kernel: conv+act (no rounding in between), conv -> BN(+act) (conv output stored, then
-    one rounding after the activation), BN+act+AvgPool3d (pooled from the UNROUNDED activation, rounded once)."""
+    one rounding after the activation; the batch statistics are those of the conv output BEFORE it was rounded, as the HIP conv
+    epilogue sums them), BN+act+AvgPool3d (pooled from the UNROUNDED activation, rounded once)."""
     torch.manual_seed(0)
     conv, act = torch.nn.Conv3d(8, 8, 3, 1, 1), torch.nn.LeakyReLU(0.2)
     bn, pool = torch.nn.BatchNorm3d(8).train(), torch.nn.AvgPool3d(2)
@@ -59,17 +60,42 @@ def test_fusion_plan_rounding_points():
     y = OB.run_seq([conv, act], x)
     assert torch.equal(y, OB.rbf(act(OB.conv_q(conv, x))))
     bn2 = torch.nn.BatchNorm3d(8).train()
-    bn2.load_state_dict(bn.state_dict())
     y = OB.run_seq([conv, bn, act, pool], x)
-    c = OB.rbf(OB.conv_q(conv, x))
-    want = OB.rbf(pool(act(bn2(c))))
-    assert torch.equal(y, want) and not torch.equal(y, OB.rbf(pool(OB.rbf(act(bn2(c))))))
-    # a pool the BatchNorm pass cannot absorb (kernel 3) stays a pass of its own: two roundings
+    t = OB.conv_q(conv, x)
+    c = OB.rbf(t)
+    want = OB.rbf(pool(act(OB.bn_from(bn2, c, t))))
+    assert torch.equal(y, want) and not torch.equal(y, OB.rbf(pool(OB.rbf(act(OB.bn_from(torch.nn.BatchNorm3d(8).train(), c, t))))))
+    assert torch.allclose(bn.running_mean, bn2.running_mean) and torch.allclose(bn.running_var, bn2.running_var) and int(bn.num_batches_tracked) == 1
+    # a pool the BatchNorm pass cannot absorb (kernel 4) stays a pass of its own: two roundings
     bn3 = torch.nn.BatchNorm3d(8).train()
     pool3 = torch.nn.AvgPool3d((1, 4, 4))
     y = OB.run_seq([conv, bn3, act, pool3], x)
-    bn4 = torch.nn.BatchNorm3d(8).train()
-    assert torch.equal(y, OB.rbf(pool3(OB.rbf(act(bn4(c))))))
+    assert torch.equal(y, OB.rbf(pool3(OB.rbf(act(OB.bn_from(torch.nn.BatchNorm3d(8).train(), c, t))))))
+    # a BatchNorm that no conv epilogue feeds (Linear -> BatchNorm1d, anogan NetG.layer1): statistics of the stored tensor
+    lin, bn1 = torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16).train()
+    z = OB.rbf(torch.randn(6, 8))
+    assert torch.equal(OB.run_seq([lin, bn1, torch.nn.ReLU()], z),
+                       OB.rbf(torch.relu(torch.nn.BatchNorm1d(16).train()(OB.rbf(OB.conv_q(lin, z))))))
+
+
+def test_bn_from_equals_torch_batchnorm_when_the_statistics_are_its_own():
+    """bn_from(bn, x, t = x) is torch's training-mode BatchNorm, forward, backward and running statistics (its backward is the
+    formula of csrc/bn.hip restated)."""
+    torch.manual_seed(1)
+    x = torch.randn(3, 5, 2, 6, 6) * 2 + 0.7
+    a, b = torch.nn.BatchNorm3d(5).train(), torch.nn.BatchNorm3d(5).train()
+    with torch.no_grad():
+        for m in (a, b):
+            m.weight.copy_(torch.tensor([1.0, 0.5, 2.0, 1.5, 0.1]))
+            m.bias.copy_(torch.tensor([0.0, 0.3, -0.2, 1.0, 0.5]))
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = a(xa), OB.bn_from(b, xb, xb)
+    g = torch.randn_like(x)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(ya, yb, atol=2e-6) and torch.allclose(xa.grad, xb.grad, atol=2e-6)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-5, atol=1e-5) and torch.allclose(a.bias.grad, b.bias.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a.running_mean, b.running_mean, atol=1e-6) and torch.allclose(a.running_var, b.running_var, atol=1e-6)
 
 
 def test_anogan_and_mygan_faithful_forward_run_and_store_bf16():

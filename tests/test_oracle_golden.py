@@ -181,3 +181,24 @@ def test_mygan_netg_224():
     with torch.no_grad():
         out = g(seeded_tensor((1, 3, 16, 224, 224), R["seeds"]["inp"]))
     check_summary(out, R["predict"], 1e-4, "predict@224")
+
+
+@pytest.mark.parametrize("name", ["autoencoder", "xception"])
+def test_supervised_baselines_step(name):
+    """the oracle's restatement of models/mystcnn.py AutoEncoder / models/xception.py Xception and of the
+    lib/train_stcnn.py:103-108 step against the vectors of the reference's own classes (16x128x128, B=1)."""
+    from vfd_oracle import mystcnn as OMS, xception as OX
+    R = JS["baselines"][name]
+    m = fill_module({"autoencoder": OMS.AutoEncoder, "xception": OX.Xception}[name](), R["seeds"]["net"]).train()
+    assert list(m.state_dict().keys()) == R["keys"] and sum(p.numel() for p in m.parameters()) == R["n_params"]
+    for mm in m.modules():
+        if isinstance(mm, nn.Dropout):
+            mm.p = 0.0
+    inp = seeded_tensor((1, 3, 16, 128, 128), R["seeds"]["inp"])
+    gt = (seeded_tensor((1, 1, 16, 128, 128), R["seeds"]["gt"], 0.0, 1.0) > 0.97).float()
+    errs, predict = OMS.step(m, OMS.make_optimizer(m), inp, gt)
+    check_errs(errs, R["step_p0"]["errs"], RT, name)
+    check_summary(predict, R["step_p0"]["predict"], 1e-4, name + " predict")
+    sd = m.state_dict()
+    for k, ref in R["after1"].items():
+        check_summary(sd[k].float(), ref, 1e-4, k)

@@ -84,6 +84,11 @@ SIGNATURES = {
     "vfd_avgpool_backward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 8 + [c_vp]),
     "vfd_upsample2x_forward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 5 + [c_vp]),
     "vfd_upsample2x_backward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 5 + [c_vp]),
+    "vfd_upsample_forward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 8 + [c_vp]),
+    "vfd_upsample_backward": (c_int, [c_int, c_vp, c_vp] + [c_int] * 8 + [c_vp]),
+    "vfd_maxpool_forward": (c_int, [c_int, c_vp, c_vp, c_vp] + [c_int] * 14 + [c_vp]),
+    "vfd_maxpool_backward": (c_int, [c_int, c_vp, c_vp, c_vp] + [c_int] * 14 + [c_vp]),
+    "vfd_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "vfd_upsample2x_cat_forward": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_upsample2x_cat_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_morph_open5x5": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_int, c_vp]),

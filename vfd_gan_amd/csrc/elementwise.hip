@@ -170,6 +170,25 @@ __global__ __launch_bounds__(256) void pack_filters_kernel(const long long* __re
   else pack_tile<float>(reinterpret_cast<const float*>(j[0]), reinterpret_cast<float*>(j[1]), A, B, Tn, tr, r, cb * 64, tb * 64, tile);
 }
 
+// ---- y = a + b (+ c): the residual joins of models/xception.py:68 (`x += skip`) and the sum of the gradients that come back to
+// a tensor with several consumers (functional.fanout), summed in float32 and rounded ONCE (torch's own bf16 adds round per term)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c, T* __restrict__ y, long long n8) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float u[8], v[8];
+    load8(a + i * 8, u);
+    load8(b + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] += v[k];
+    if (c != nullptr) {
+      load8(c + i * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u[k] += v[k];
+    }
+    store8(y + i * 8, u);
+  }
+}
+
 // ---- activation ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int act, float slope) {
@@ -477,6 +496,18 @@ extern "C" int vfd_pack_filters(const int64_t* jobs_dev, int njobs, int64_t tota
   hipLaunchKernelGGL(pack_filters_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const long long*>(jobs_dev), njobs);
   VFD_CHECK_LAUNCH("pack_filters");
+  return VFD_OK;
+}
+
+extern "C" int vfd_add(int dtype, const void* a, const void* b, const void* c, void* y, int64_t n, void* stream) {
+  CHECK_DTYPE(dtype, "add");
+  VFD_REQUIRE(a && b && y && n > 0 && (n & 7) == 0, "add: bad arguments (element count must be a multiple of 8: channels-last blocks are)");
+  const long long n8 = n >> 3;
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)c, (bf16_t*)y, n8);
+  else
+    hipLaunchKernelGGL(add_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)a, (const float*)b, (const float*)c, (float*)y, n8);
+  VFD_CHECK_LAUNCH("add");
   return VFD_OK;
 }
 

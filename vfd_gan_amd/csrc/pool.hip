@@ -116,9 +116,11 @@ __device__ __forceinline__ void up_src(int o, int I, int O, int& i0, int& i1, fl
   l1 = s - (float)i0;
 }
 
+// (Do, Ho, Wo) = per-dimension output extents: 2x the input for the U-Net's Upsample(2), or (D, 2H, 2W) for the (1,2,2) scale of
+// models/xception.py:84 — an extent equal to the input's makes that dimension the identity (src = o, weight 1)
 template <typename T>
-__global__ void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W, int Cp) {
-  const int GR = Cp >> 3, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+__global__ void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int D, int H, int W, int Cp, int Do, int Ho, int Wo) {
+  const int GR = Cp >> 3;
   const long long total = (long long)N * Do * Ho * Wo * GR;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     long long q = i;
@@ -218,8 +220,9 @@ __global__ void slice_copy_kernel(const T* __restrict__ src, T* __restrict__ dst
 
 // dyCp: row length of dy (>= Cp: the gradient may be the leading channels of a wider, concatenated tensor)
 template <typename T>
-__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int D, int H, int W, int Cp, int dyCp) {
-  const int GR = Cp >> 3, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int D, int H, int W, int Cp, int dyCp, int Do, int Ho, int Wo) {
+  const int GR = Cp >> 3;
+  const int fd = Do / D, fh = Ho / H, fw = Wo / W;     // 1 or 2 per dimension
   const long long total = (long long)N * D * H * W * GR;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     long long q = i;
@@ -229,14 +232,14 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
     const int id = (int)(q % D); q /= D;
     const int n = (int)q;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // src(o) in (i-1, i+1)  =>  o in [2i-2, 2i+3]  because 1/r = 2 + 1/(I-1)
-    for (int od = max(0, 2 * id - 2); od <= min(Do - 1, 2 * id + 3); ++od) {
+    // src(o) in (i-1, i+1)  =>  o in [f i - 2, f i + 3]  (f = 2: 1/r = 2 + 1/(I-1); f = 1: o == i, inside the range)
+    for (int od = max(0, fd * id - 2); od <= min(Do - 1, fd * id + 3); ++od) {
       const float wd = up_weight(od, id, D, Do);
       if (wd == 0.f) continue;
-      for (int oh = max(0, 2 * ih - 2); oh <= min(Ho - 1, 2 * ih + 3); ++oh) {
+      for (int oh = max(0, fh * ih - 2); oh <= min(Ho - 1, fh * ih + 3); ++oh) {
         const float wh = up_weight(oh, ih, H, Ho);
         if (wh == 0.f) continue;
-        for (int ow = max(0, 2 * iw - 2); ow <= min(Wo - 1, 2 * iw + 3); ++ow) {
+        for (int ow = max(0, fw * iw - 2); ow <= min(Wo - 1, fw * iw + 3); ++ow) {
           const float ww = up_weight(ow, iw, W, Wo);
           if (ww == 0.f) continue;
           const size_t pix = ((size_t)(n * Do + od) * Ho + oh) * Wo + ow;
@@ -248,6 +251,89 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ 
         }
       }
     }
+    store8(dx + i * 8, s);
+  }
+}
+
+// MaxPool3d (models/xception.py:57: kernel (1,3,3), stride (1,s,s), padding (0,1,1)), any kernel of <= 255 taps with padding.
+// torch semantics: the window is clipped to the input, the FIRST maximum in (d,h,w) scan order wins (strict >), a NaN wins.
+// The forward also stores, per output element, the window-local index of its maximum (1 byte), so that the backward is a
+// gather: an input element receives dy of every window whose stored index names it (deterministic, no atomics).
+struct PoolGeom { int kd, kh, kw, sd, sh, sw, pd, ph, pw; };
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int N, int D, int H, int W,
+                                   int Cp, int Do, int Ho, int Wo, PoolGeom g_) {
+  const int GR = Cp >> 3;
+  const long long total = (long long)N * Do * Ho * Wo * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long q = i;
+    const int g = (int)(q % GR); q /= GR;
+    const int ow = (int)(q % Wo); q /= Wo;
+    const int oh = (int)(q % Ho); q /= Ho;
+    const int od = (int)(q % Do); q /= Do;
+    const int n = (int)q;
+    float m[8];
+    uint32_t mi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; mi[k] = 0xffu; }
+    for (int a = 0; a < g_.kd; ++a) {
+      const int id = od * g_.sd - g_.pd + a;
+      if ((unsigned)id >= (unsigned)D) continue;
+      for (int b = 0; b < g_.kh; ++b) {
+        const int ih = oh * g_.sh - g_.ph + b;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int c = 0; c < g_.kw; ++c) {
+          const int iw = ow * g_.sw - g_.pw + c;
+          if ((unsigned)iw >= (unsigned)W) continue;
+          const uint32_t t = (uint32_t)((a * g_.kh + b) * g_.kw + c);
+          float v[8];
+          load8(x + ((((size_t)n * D + id) * H + ih) * W + iw) * Cp + g * 8, v);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (v[k] > m[k] || v[k] != v[k] || mi[k] == 0xffu) { m[k] = v[k]; mi[k] = t; }
+        }
+      }
+    }
+    store8(y + i * 8, m);
+    uint2 o;
+    o.x = mi[0] | (mi[1] << 8) | (mi[2] << 16) | (mi[3] << 24);
+    o.y = mi[4] | (mi[5] << 8) | (mi[6] << 16) | (mi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = o;
+  }
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* __restrict__ dx, int N, int D, int H,
+                                   int W, int Cp, int Do, int Ho, int Wo, PoolGeom g_) {
+  const int GR = Cp >> 3;
+  const long long total = (long long)N * D * H * W * GR;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long q = i;
+    const int g = (int)(q % GR); q /= GR;
+    const int iw = (int)(q % W); q /= W;
+    const int ih = (int)(q % H); q /= H;
+    const int id = (int)(q % D); q /= D;
+    const int n = (int)q;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // windows that contain this element: o*s - p <= i <= o*s - p + k - 1
+    const int od0 = max(0, (id + g_.pd - g_.kd + g_.sd) / g_.sd), od1 = min(Do - 1, (id + g_.pd) / g_.sd);
+    const int oh0 = max(0, (ih + g_.ph - g_.kh + g_.sh) / g_.sh), oh1 = min(Ho - 1, (ih + g_.ph) / g_.sh);
+    const int ow0 = max(0, (iw + g_.pw - g_.kw + g_.sw) / g_.sw), ow1 = min(Wo - 1, (iw + g_.pw) / g_.sw);
+    for (int od = od0; od <= od1; ++od)
+      for (int oh = oh0; oh <= oh1; ++oh)
+        for (int ow = ow0; ow <= ow1; ++ow) {
+          const uint32_t t = (uint32_t)(((id - (od * g_.sd - g_.pd)) * g_.kh + (ih - (oh * g_.sh - g_.ph))) * g_.kw + (iw - (ow * g_.sw - g_.pw)));
+          const size_t o = ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * Cp + g * 8;
+          const uint2 w = *reinterpret_cast<const uint2*>(idx + o);
+          float v[8];
+          load8(dy + o, v);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const uint32_t mk = ((k < 4 ? w.x : w.y) >> (8 * (k & 3))) & 0xffu;
+            if (mk == t) s[k] += v[k];
+          }
+        }
     store8(dx + i * 8, s);
   }
 }
@@ -300,10 +386,82 @@ extern "C" int vfd_upsample2x_forward(int dtype, const void* x, void* y, int N, 
   const int Cp = cpad(C);
   const long long total = (long long)N * D * H * W * 8 * (Cp >> 3);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, N, D, H, W, Cp);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, N, D, H, W, Cp, 2 * D, 2 * H, 2 * W);
   else
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, N, D, H, W, Cp);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, N, D, H, W, Cp, 2 * D, 2 * H, 2 * W);
   VFD_CHECK_LAUNCH("upsample2x_forward");
+  return VFD_OK;
+}
+
+// Upsample(scale_factor=(fd,fh,fw), mode='trilinear', align_corners=True) with every factor 1 or 2 (models/xception.py:84: (1,2,2))
+extern "C" int vfd_upsample_forward(int dtype, const void* x, void* y, int N, int D, int H, int W, int C, int fd, int fh, int fw, void* stream) {
+  POOL_ARGS_OK("upsample_forward");
+  VFD_REQUIRE(x && y && (fd == 1 || fd == 2) && (fh == 1 || fh == 2) && (fw == 1 || fw == 2), "upsample_forward: scale factors must be 1 or 2");
+  const int Cp = cpad(C);
+  const long long total = (long long)N * D * fd * H * fh * W * fw * (Cp >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, N, D, H, W, Cp, fd * D, fh * H, fw * W);
+  else
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, N, D, H, W, Cp, fd * D, fh * H, fw * W);
+  VFD_CHECK_LAUNCH("upsample_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_upsample_backward(int dtype, const void* dy, void* dx, int N, int D, int H, int W, int C, int fd, int fh, int fw, void* stream) {
+  POOL_ARGS_OK("upsample_backward");
+  VFD_REQUIRE(dy && dx && (fd == 1 || fd == 2) && (fh == 1 || fh == 2) && (fw == 1 || fw == 2), "upsample_backward: scale factors must be 1 or 2");
+  const int Cp = cpad(C);
+  const long long total = (long long)N * D * H * W * (Cp >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, Cp, Cp, fd * D, fh * H, fw * W);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, N, D, H, W, Cp, Cp, fd * D, fh * H, fw * W);
+  VFD_CHECK_LAUNCH("upsample_backward");
+  return VFD_OK;
+}
+
+static int maxpool_geom(int D, int H, int W, const PoolGeom& g, int& Do, int& Ho, int& Wo) {
+  VFD_REQUIRE(g.kd > 0 && g.kh > 0 && g.kw > 0 && g.sd > 0 && g.sh > 0 && g.sw > 0 && g.pd >= 0 && g.ph >= 0 && g.pw >= 0, "maxpool: bad kernel / stride / padding");
+  VFD_REQUIRE(g.kd * g.kh * g.kw <= 255 && 2 * g.pd <= g.kd && 2 * g.ph <= g.kh && 2 * g.pw <= g.kw, "maxpool: at most 255 taps, padding at most half the kernel");
+  VFD_REQUIRE(D + 2 * g.pd >= g.kd && H + 2 * g.ph >= g.kh && W + 2 * g.pw >= g.kw, "maxpool: kernel larger than the padded input");
+  Do = (D + 2 * g.pd - g.kd) / g.sd + 1; Ho = (H + 2 * g.ph - g.kh) / g.sh + 1; Wo = (W + 2 * g.pw - g.kw) / g.sw + 1;     // floor mode
+  return VFD_OK;
+}
+
+// y [N,Do,Ho,Wo,CPAD(C)], idx (uint8, same shape): window-local index of each output's maximum, for vfd_maxpool_backward
+extern "C" int vfd_maxpool_forward(int dtype, const void* x, void* y, void* idx, int N, int D, int H, int W, int C, int kd, int kh, int kw,
+                                   int sd, int sh, int sw, int pd, int ph, int pw, void* stream) {
+  POOL_ARGS_OK("maxpool_forward");
+  VFD_REQUIRE(x && y && idx, "maxpool_forward: null pointer");
+  const PoolGeom g = {kd, kh, kw, sd, sh, sw, pd, ph, pw};
+  int Do, Ho, Wo;
+  const int rc = maxpool_geom(D, H, W, g, Do, Ho, Wo);
+  if (rc != VFD_OK) return rc;
+  const int Cp = cpad(C);
+  const long long total = (long long)N * Do * Ho * Wo * (Cp >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, (uint8_t*)idx, N, D, H, W, Cp, Do, Ho, Wo, g);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)x, (float*)y, (uint8_t*)idx, N, D, H, W, Cp, Do, Ho, Wo, g);
+  VFD_CHECK_LAUNCH("maxpool_forward");
+  return VFD_OK;
+}
+
+extern "C" int vfd_maxpool_backward(int dtype, const void* dy, const void* idx, void* dx, int N, int D, int H, int W, int C, int kd, int kh,
+                                    int kw, int sd, int sh, int sw, int pd, int ph, int pw, void* stream) {
+  POOL_ARGS_OK("maxpool_backward");
+  VFD_REQUIRE(dy && idx && dx, "maxpool_backward: null pointer");
+  const PoolGeom g = {kd, kh, kw, sd, sh, sw, pd, ph, pw};
+  int Do, Ho, Wo;
+  const int rc = maxpool_geom(D, H, W, g, Do, Ho, Wo);
+  if (rc != VFD_OK) return rc;
+  const int Cp = cpad(C);
+  const long long total = (long long)N * D * H * W * (Cp >> 3);
+  if (dtype == VFD_BF16)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (const uint8_t*)idx, (bf16_t*)dx, N, D, H, W, Cp, Do, Ho, Wo, g);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (const uint8_t*)idx, (float*)dx, N, D, H, W, Cp, Do, Ho, Wo, g);
+  VFD_CHECK_LAUNCH("maxpool_backward");
   return VFD_OK;
 }
 
@@ -313,9 +471,9 @@ extern "C" int vfd_upsample2x_backward(int dtype, const void* dy, void* dx, int 
   const int Cp = cpad(C);
   const long long total = (long long)N * D * H * W * (Cp >> 3);
   if (dtype == VFD_BF16)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, Cp, Cp);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, N, D, H, W, Cp, Cp, 2 * D, 2 * H, 2 * W);
   else
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, N, D, H, W, Cp, Cp);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, as_stream(stream), (const float*)dy, (float*)dx, N, D, H, W, Cp, Cp, 2 * D, 2 * H, 2 * W);
   VFD_CHECK_LAUNCH("upsample2x_backward");
   return VFD_OK;
 }
@@ -347,10 +505,10 @@ extern "C" int vfd_upsample2x_cat_backward(int dtype, const void* dcat, void* dx
   const long long tot2 = orows * (Cbp >> 3);
   hipStream_t st = as_stream(stream);
   if (dtype == VFD_BF16) {
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const bf16_t*)dcat, (bf16_t*)dx, N, D, H, W, Ca, Ccat);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const bf16_t*)dcat, (bf16_t*)dx, N, D, H, W, Ca, Ccat, 2 * D, 2 * H, 2 * W);
     hipLaunchKernelGGL(slice_copy_kernel<bf16_t>, dim3(pl_blocks(tot2)), dim3(PL_THREADS), 0, st, (const bf16_t*)dcat, (bf16_t*)dskip, orows, Ccat, Ca >> 3, Cbp >> 3);
   } else {
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const float*)dcat, (float*)dx, N, D, H, W, Ca, Ccat);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(pl_blocks(total)), dim3(PL_THREADS), 0, st, (const float*)dcat, (float*)dx, N, D, H, W, Ca, Ccat, 2 * D, 2 * H, 2 * W);
     hipLaunchKernelGGL(slice_copy_kernel<float>, dim3(pl_blocks(tot2)), dim3(PL_THREADS), 0, st, (const float*)dcat, (float*)dskip, orows, Ccat, Ca >> 3, Cbp >> 3);
   }
   VFD_CHECK_LAUNCH("upsample2x_cat_backward");

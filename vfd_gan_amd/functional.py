@@ -1086,6 +1086,125 @@ def upsample_trilinear2x(x):
     return ClTensor(_Upsample2x.apply(x.t, x.C), x.C, x.nsp)
 
 
+class _UpsampleN(torch.autograd.Function):
+    """nn.Upsample(scale_factor=(fd,fh,fw), trilinear, align_corners=True) with factors 1 or 2 (vfd_upsample_*)."""
+
+    @staticmethod
+    def forward(ctx, x, C, f):
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        y = torch.empty((N, f[0] * D, f[1] * H, f[2] * W, Cp), dtype=x.dtype, device=x.device)
+        check(load().vfd_upsample_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), N, D, H, W, C, f[0], f[1], f[2], stream()),
+              "upsample_forward")
+        ctx.meta = (N, D, H, W, C, f, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, D, H, W, C, f, shape = ctx.meta
+        gy = gy.contiguous()
+        dx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        check(load().vfd_upsample_backward(dtype_code(gy.dtype), gy.data_ptr(), dx.data_ptr(), N, D, H, W, C, f[0], f[1], f[2], stream()),
+              "upsample_backward")
+        return dx, None, None
+
+
+def upsample_trilinear(x, factors):
+    """Upsample(scale_factor=factors, mode='trilinear', align_corners=True), every factor 1 or 2 (models/xception.py:84)."""
+    f = tuple(int(v) for v in _triple(factors, 3, 1))
+    if x.nsp != 3 or any(v not in (1, 2) for v in f):
+        raise NotImplementedError("upsample_trilinear: (N,C,D,H,W) blocks and scale factors 1 or 2 only, got %s" % (f,))
+    if f == (2, 2, 2):
+        return upsample_trilinear2x(x)
+    return ClTensor(_UpsampleN.apply(x.t, x.C, f), x.C, x.nsp)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, C, k, s, p):
+        x = x.contiguous()
+        N, D, H, W, Cp = x.shape
+        out = tuple((v + 2 * pp - kk) // ss + 1 for v, kk, ss, pp in zip((D, H, W), k, s, p))
+        y = torch.empty((N,) + out + (Cp,), dtype=x.dtype, device=x.device)
+        idx = torch.empty((N,) + out + (Cp,), dtype=torch.uint8, device=x.device)
+        check(load().vfd_maxpool_forward(dtype_code(x.dtype), x.data_ptr(), y.data_ptr(), idx.data_ptr(), N, D, H, W, C, *k, *s, *p, stream()),
+              "maxpool_forward")
+        ctx.meta = (N, D, H, W, C, k, s, p, tuple(x.shape))
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, D, H, W, C, k, s, p, shape = ctx.meta
+        (idx,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = torch.empty(shape, dtype=gy.dtype, device=gy.device)
+        check(load().vfd_maxpool_backward(dtype_code(gy.dtype), gy.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, D, H, W, C, *k, *s, *p,
+                                          stream()), "maxpool_backward")
+        return dx, None, None, None, None
+
+
+def max_pool(x, kernel, stride=None, padding=0):
+    """nn.MaxPool3d(kernel, stride, padding) on an (N,C,D,H,W) block (models/xception.py:57)."""
+    k = _triple(kernel, 3, 1)
+    s = _triple(stride if stride is not None else kernel, 3, 1)
+    p = _triple(padding, 3, 0)
+    return ClTensor(_MaxPool.apply(x.t, x.C, tuple(k), tuple(s), tuple(p)), x.C, x.nsp)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        check(load().vfd_add(dtype_code(a.dtype), a.data_ptr(), b.data_ptr(), 0, y.data_ptr(), a.numel(), stream()), "add")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """a + b of two equally shaped blocks (the residual join `x += skip` of models/xception.py:68)."""
+    if tuple(a.t.shape) != tuple(b.t.shape) or a.C != b.C:
+        raise RuntimeError("add: shapes differ: %s vs %s" % (a.shape, b.shape))
+    return ClTensor(_Add.apply(a.t, b.t), a.C, a.nsp)
+
+
+class _Fanout(torch.autograd.Function):
+    """n aliases of one tensor whose gradients are summed by ONE launch (float32 sum, one rounding) instead of autograd's
+    pairwise adds in the storage dtype: a tensor with several consumers (ganomaly's fake: L1 loss, encoder2, netD)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        acc = gs[0]
+        lib = load()
+        i = 1
+        while i < len(gs):
+            c = gs[i + 1] if i + 1 < len(gs) else None
+            y = torch.empty_like(acc)
+            check(lib.vfd_add(dtype_code(acc.dtype), acc.data_ptr(), gs[i].data_ptr(), ptr(c), y.data_ptr(), acc.numel(), stream()), "add")
+            acc = y
+            i += 2
+        return acc, None
+
+
+def fanout(x, n):
+    """`n` handles of the block x for n consumers; see _Fanout."""
+    return tuple(ClTensor(t, x.C, x.nsp) for t in _Fanout.apply(x.t, n))
+
+
 class _UpsampleCat(torch.autograd.Function):
     """torch.cat([Upsample(scale 2, trilinear, align_corners)(x), skip], dim=1) without the up-sampled intermediate."""
 

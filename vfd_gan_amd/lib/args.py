@@ -28,7 +28,7 @@ class Args():
 
         # Network
         self.parser.add_argument('--model', default="mygan", type=str,
-                                 help='train model: mygan | anogan | ganomaly. Default=mygan')
+                                 help='train model: mygan | anogan | ganomaly | c2plus1d | xception. Default=mygan')
 
         # Train
         self.parser.add_argument('--lr', default=2e-5, type=float, help='initial learning rate for adam. Default=2e-5')
@@ -40,7 +40,7 @@ class Args():
                                  help='frequency of update tensorboard and test. Default=50')
         self.parser.add_argument('--resume', default="", type=str, help='Pretrained Model weight path for training')
         self.parser.add_argument('--ae', default=False, action="store_true",
-                                 help='Use AutoEncoder on c2plus1d net as Generator (unsupported: broken in the reference)')
+                                 help='Use AutoEncoder on c2plus1d net as Generator')
 
         # build-only switches
         self.parser.add_argument('--dtype', default="bf16", choices=["bf16", "f32", "fp8"],

@@ -191,9 +191,12 @@ class MyGAN(GANBaseModel):
     def __init__(self, args, dataloader):
         super(MyGAN, self).__init__(args, dataloader)
         if getattr(args, "ae", False):
-            raise NotImplementedError("--ae (AutoEncoder generator) cannot run in the reference either "
-                                      "(models/mygannet.py:224-227 builds an instance and then calls it)")
-        self.netg = NetG(getattr(args, "ich", 3)).to(self.device)
+            # reference :224-227 means this (`netg = AutoEncoder()`), but then CALLS the instance without an input where it
+            # should hand it over (:233 / :239), so --ae cannot run there; here the (2+1)D auto-encoder baseline is the generator
+            from .mystcnn import AutoEncoder
+            self.netg = AutoEncoder().to(self.device)
+        else:
+            self.netg = NetG(getattr(args, "ich", 3)).to(self.device)
         self.netd = NetD(args).to(self.device)
         self.netg.apply(weights_init)
         self.netd.apply(weights_init)

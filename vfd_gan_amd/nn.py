@@ -178,15 +178,31 @@ class AvgPool3d(tnn.AvgPool3d):
         return F.avg_pool(x, k)
 
 
+class MaxPool3d(tnn.MaxPool3d):
+    """nn.MaxPool3d (models/xception.py:57); floor mode, no dilation, no indices."""
+
+    def forward(self, x):
+        _need_cl(x, "MaxPool3d")
+        if self.ceil_mode or self.return_indices or F._triple(self.dilation, 3, 1) != (1, 1, 1):
+            raise NotImplementedError("MaxPool3d: ceil_mode / return_indices / dilation are not used by the reference nets")
+        return F.max_pool(x, self.kernel_size, self.stride, self.padding)
+
+
 class Upsample(tnn.Upsample):
+    def factors(self):
+        sf = self.scale_factor
+        f = tuple(float(v) for v in sf) if isinstance(sf, (tuple, list)) else (float(sf),) * 3
+        if not (self.mode == "trilinear" and self.align_corners and len(f) == 3 and all(v in (1.0, 2.0) for v in f)):
+            raise NotImplementedError("only Upsample(scale_factor in {1,2}^3, mode='trilinear', align_corners=True)")
+        return tuple(int(v) for v in f)
+
     def check(self):
-        if not (self.mode == "trilinear" and self.align_corners and float(self.scale_factor) == 2.0):
+        if self.factors() != (2, 2, 2):
             raise NotImplementedError("only Upsample(scale_factor=2, mode='trilinear', align_corners=True)")
 
     def forward(self, x):
         _need_cl(x, "Upsample")
-        self.check()
-        return F.upsample_trilinear2x(x)
+        return F.upsample_trilinear(x, self.factors())
 
 
 class Dropout(tnn.Dropout):

@@ -1,9 +1,9 @@
 """Dispatcher with the behaviour of the reference's trainer.py:7-56 for the GAN models.
 
 ``python -m vfd_gan_amd.trainer --model {mygan,anogan,ganomaly} ...`` (or under torchrun for one process per GPU:
-the reference's ``--gpu 0,1`` DataParallel is replaced by RCCL data parallelism, vfd_gan_amd/dist.py).  The
-supervised baselines (c2plus1d / xception / clstm -> lib/train_stcnn.py) are outside the hot path
- and are rejected with the reference's own "is None" message.
+the reference's ``--gpu 0,1`` DataParallel is replaced by RCCL data parallelism, vfd_gan_amd/dist.py).  Of the
+supervised baselines (lib/train_stcnn.py) ``c2plus1d`` and ``xception`` are built on the hot path's kernels;
+``clstm`` (models/convlstm.py) is not and is rejected with the reference's own "is None" message.
 """
 from __future__ import print_function
 
@@ -23,6 +23,9 @@ def build_model(args, dataloader):
     if args.model == 'ganomaly':
         from .models.ganomaly import Ganomaly
         return Ganomaly(args, dataloader)
+    if args.model in ('c2plus1d', 'xception'):          # the supervised (2+1)D / Xception baselines (reference trainer.py:29-34)
+        from .lib.train_stcnn import VFD_STCNN
+        return VFD_STCNN(args, dataloader)
     print("\n %s is None." % (args.model))
     exit()
 
