@@ -101,13 +101,14 @@ int64_t vfd_pack_filter_blocks(int A, int B, int T, int transpose_ab);
 int vfd_pack_filters(const int64_t* jobs_dev, int njobs, int64_t total_blocks, void* stream);
 
 /* y = act(conv(x, packed) + bias).  `bias` float32[Cout] or NULL.
- * When stats != NULL (float32 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates
+ * When stats != NULL (float64 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates
  * the per-channel sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
- * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106), one float atomic per
- * channel and workgroup, spread over replica rows; vfd_bn_stats_from_sums folds the replicas.                */
+ * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106), summed in DOUBLE from the float32
+ * accumulators on (the variance is formed as E[x^2] - mean^2: float32 sums lose (|mean|/sigma)^2 digits there), one
+ * atomic per channel and workgroup, spread over replica rows; vfd_bn_stats_from_sums / vfd_bn_act_forward_sums fold them. */
 #define VFD_STATS_REPLICAS 8
 int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
-                     float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
+                     double* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
 /* Scratch bytes vfd_conv_forward wants for `d` (0 for most shapes).  Convolutions with few output pixels and a
  * long reduction (ganomaly Encoder final conv / NetD classifier: 512 pixels x K=25088) split K over workgroups
  * into float32 partial tiles in `ws` and fold them in a finish kernel; without `ws` they run unsplit.      */
@@ -128,7 +129,7 @@ int vfd_pack_filter_fp8(const float* w, void* packed, int A, int B, int T, int t
                         float* scale_out, void* stream);
 int vfd_dequantize_fp8(const void* q, float* y, int64_t n, const float* scale, void* stream);
 int vfd_conv_forward_fp8(const vfd_conv_desc* d, const void* x, const float* scale_x, const void* packed,
-                         const float* scale_w, const float* bias, void* y, float* stats, size_t stats_bytes,
+                         const float* scale_w, const float* bias, void* y, double* stats, size_t stats_bytes,
                          void* stream);
 
 /* y = (conv(x, packed) + bias) * act'(mul_src), mul_src a tensor of y's shape and dtype holding the OUTPUT of an
@@ -187,9 +188,10 @@ int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float be
  * layer's bias gradient = the column sums of its output gradient, left there by whoever produced that gradient — the
  * consuming BatchNorm's apply pass (vfd_bn_backward_apply_sums, rep_stride = CPAD(Cout)) or the consuming convolution's
  * data-gradient launch run with a statistics buffer (conv -> conv chains, models/anogan.py:51-52,85-86: the sum row of
- * [VFD_STATS_REPLICAS][2][CPAD(Cout)], rep_stride = 2 * CPAD(Cout)).                                              */
-int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
-                          int rep_stride, float* db, void* stream);
+ * [VFD_STATS_REPLICAS][2][CPAD(Cout)], rep_stride = 2 * CPAD(Cout), rep_f64 = 1: those rows are doubles; the BatchNorm's
+ * rows are float32, rep_f64 = 0).                                                                                  */
+int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const void* bias_rep,
+                          int rep_stride, int rep_f64, float* db, void* stream);
 /* Dispatch switch of the halo-tiled filter-gradient kernel (conv_wgrad_halo.hip: stride-1 layers with a 3 x 3 in-plane
  * footprint, kd 1 or 3, >= 33 channels on both sides, bf16): 0 = default rules, 1 = never (conv_wgrad's per-tap
  * gather), 2 = whenever eligible (tests).  Returns the previous mode.  vfd_wgrad_workspace / vfd_conv_wgrad /
@@ -214,7 +216,7 @@ int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float eps, float
                  float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
                  void* stream);
 /* Same, from the conv epilogue's sum / sum-of-squares buffer (stats[VFD_STATS_REPLICAS][2][Cp]).         */
-int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean,
+int vfd_bn_stats_from_sums(const double* stats, int64_t rows, int C, float eps, float momentum, float* mean,
                            float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                            void* stream);
 /* One more running-statistics update (and counter increment) from batch statistics already at hand: stands in for a
@@ -228,7 +230,7 @@ int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t rows, int C, c
                        void* stream);
 /* vfd_bn_stats_from_sums + vfd_bn_act_forward in ONE launch: every thread folds the replica rows of its 8 channels, the
  * first row of workgroups publishes mean / rstd (saved for backward), the running statistics and the counter.       */
-int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const float* sums, float eps,
+int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const double* sums, float eps,
                             float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, const float* gamma, const float* beta, int act, float slope,
                             void* stream);
@@ -250,7 +252,7 @@ int vfd_bn_act_backward(int dtype, const void* x, const void* dy, void* dx, int6
  * connection, models/mygannet.py:74-94): the forward writes it as well, and the backward adds the gradient that arrived
  * for it: dy = g_full + gpool / (pd*ph*pw) — no pooling-backward pass, no gradient-sum pass.                        */
 int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw,
-                                 int C, const float* sums,
+                                 int C, const double* sums,
                                  float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                  float* running_var, int64_t* num_batches_tracked, const float* gamma,
                                  const float* beta, int act, float slope, void* y_full, void* stream);

@@ -683,10 +683,10 @@ def test_batchnorm_activation_avgpool_fused_with_skip(dt, dev):
         m.to(dev)
     xd = x.to(dev).requires_grad_()
     k = F.stats_buffer_numel(24)
-    buf = torch.zeros(3 * k, dtype=torch.float32, device=dev)
-    tok = {"taken": False, "rep": buf[2 * k:]}
-    h = c1(F.to_cl(xd, dt), stats=buf[:k], bias_token=tok)
-    pooled, full = bn.forward_pooled(h, _lib_act_lrelu(), 0.2, buf[:k], buf[k:2 * k], c1.bias, tok, (2, 2, 2), True)
+    buf, fstats = torch.zeros(2 * k, dtype=torch.float32, device=dev), F.new_stats_buffer(24, dev)      # forward statistics: float64
+    tok = {"taken": False, "rep": buf[k:]}
+    h = c1(F.to_cl(xd, dt), stats=fstats, bias_token=tok)
+    pooled, full = bn.forward_pooled(h, _lib_act_lrelu(), 0.2, fstats, buf[:k], c1.bias, tok, (2, 2, 2), True)
     ya, yb = ca(pooled).to_torch(), cb(full).to_torch()
     ((ya.float() * ga.to(dev)).sum() + (yb.float() * gb.to(dev)).sum()).backward()
     torch.cuda.synchronize()

@@ -43,7 +43,8 @@ def main():
         mean, rstd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
         dg, db, cs = torch.empty(C, device=dev), torch.empty(C, device=dev), torch.zeros(F.stats_buffer_numel(C), device=dev)
-        sums = torch.zeros(F.stats_buffer_numel(C), device=dev)
+        sums = F.new_stats_buffer(C, dev)      # forward statistics: float64
+        bsums = torch.zeros(F.stats_buffer_numel(C), device=dev)
         ws = torch.empty(lib.vfd_bn_workspace(rows, C), dtype=torch.uint8, device=dev)
         st = stream()
 
@@ -62,7 +63,7 @@ def main():
 
         def bwd2(c=None):
             check(lib.vfd_bn_act_backward_sums(dtc, x.data_ptr(), dy.data_ptr(), dx.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(),
-                                               gamma.data_ptr(), beta.data_ptr(), 1, 0.2, sums.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                               gamma.data_ptr(), beta.data_ptr(), 1, 0.2, bsums.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                                None, None, c, st), "b2")
 
         t = [timeit(fwd), timeit(fwd_fold), timeit(bwd3), timeit(bwd2), timeit(lambda: bwd2(cs.data_ptr()))]

@@ -56,7 +56,7 @@ SIGNATURES = {
                                     ctypes.POINTER(c_sz)]),
     "vfd_conv_wgrad": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vfd_wgrad_reduce": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_f32, c_vp]),
-    "vfd_wgrad_reduce_bias": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_f32, c_vp, c_int, c_vp, c_vp]),
+    "vfd_wgrad_reduce_bias": (c_int, [ctypes.POINTER(ConvDesc), c_vp, c_vp, c_f32, c_vp, c_int, c_int, c_vp, c_vp]),
     "vfd_wgrad_set_halo_mode": (c_int, [c_int]),
     "vfd_wgrad_kernel_name": (c_int, [ctypes.POINTER(ConvDesc), ctypes.c_char_p, c_sz]),
     "vfd_bias_grad_workspace": (c_sz, [c_int]),

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-__global__ void bn_from_sums_kernel(const float* __restrict__ sums, long long rows, int C, float eps, float momentum,
+__global__ void bn_from_sums_kernel(const double* __restrict__ sums, long long rows, int C, float eps, float momentum,
                                     float* mean_o, float* rstd_o, float* rmean, float* rvar, long long* nbt) {
   if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // BatchNorm.num_batches_tracked
   const int Cp = (C + 7) & ~7;
@@ -234,11 +234,43 @@ __device__ __forceinline__ void fold_replicas8(const float* __restrict__ sums, i
   }
 }
 
+// The same for the FORWARD statistics, which the conv epilogues sum in double (conv_epilogue.hpp EpiP::stats: the variance is
+// formed as E[x^2] - mean^2 below, and float32 sums lose (|mean| / sigma)^2 digits there); sum row and square row go through
+// the LDS one after the other (18 KB instead of 35).  EVERY thread of the workgroup must call it (three barriers).
+__device__ __forceinline__ void fold_replicas8_d(const double* __restrict__ sums, int Cp, int g, bool live, int tx, int ty, int TX, int TY,
+                                                 double (*sh)[8 + 1], double (&s1)[8], double (&s2)[8]) {
+  static_assert(VFD_STATS_REPLICAS == 8, "row-lane split below");
+  const int nl = TY < VFD_STATS_REPLICAS ? TY : VFD_STATS_REPLICAS;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    double pa[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pa[k] = 0.0;
+    if (live) {
+      for (int r = ty; r < VFD_STATS_REPLICAS; r += TY) {
+        const double2* a = reinterpret_cast<const double2*>(sums + (size_t)r * 2 * Cp + (size_t)half * Cp + g * 8);
+        const double2 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+        pa[0] += a0.x; pa[1] += a0.y; pa[2] += a1.x; pa[3] += a1.y; pa[4] += a2.x; pa[5] += a2.y; pa[6] += a3.x; pa[7] += a3.y;
+      }
+    }
+    if (half) __syncthreads();      // every lane is done with the first half's partials
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[threadIdx.x][k] = pa[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double v = 0.0;
+      for (int j = 0; j < nl; ++j) v += sh[j * TX + tx][k];
+      if (half) s2[k] = v; else s1[k] = v;
+    }
+  }
+}
+
 // batch statistics handed over as epilogue sums (SUMS): the fold that bn_from_sums_kernel does in a launch of its own is
 // repeated by every thread for its 8 channels (32 L2-resident 16-byte loads); the row-0 workgroups publish mean / rstd
 // (saved for backward) and update the running statistics.
 struct BnSumsArg {
-  const float* sums;
+  const double* sums;      // [VFD_STATS_REPLICAS][2][Cp] doubles (conv epilogue statistics)
   float eps, momentum;
   float* mean_o;
   float* rstd_o;
@@ -280,11 +312,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   const int Cp = (C + 7) & ~7, GR = Cp >> 3;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
   const int g = blockIdx.x * TX + tx;
-  __shared__ float sh_fold[SUMS ? 256 : 1][16 + 1];
+  __shared__ double sh_fold[SUMS ? 256 : 1][8 + 1];
   double s1[8], s2[8];
   if constexpr (SUMS) {
     if (sa.nbt != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *sa.nbt += 1;      // BatchNorm.num_batches_tracked
-    fold_replicas8(sa.sums, Cp, g, g < GR, tx, ty, TX, TY, sh_fold, s1, s2);
+    fold_replicas8_d(sa.sums, Cp, g, g < GR, tx, ty, TX, TY, sh_fold, s1, s2);
   }
   if (g >= GR) return;
   float sc[8], sf[8];
@@ -741,7 +773,7 @@ extern "C" int vfd_bn_stats(int dtype, const void* x, int64_t rows, int C, float
   return VFD_OK;
 }
 
-extern "C" int vfd_bn_stats_from_sums(const float* stats, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
+extern "C" int vfd_bn_stats_from_sums(const double* stats, int64_t rows, int C, float eps, float momentum, float* mean, float* rstd,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
   VFD_REQUIRE(stats && mean && rstd && rows > 0 && C > 0, "bn_stats_from_sums: bad arguments");
   hipLaunchKernelGGL(bn_from_sums_kernel, dim3((C + 127) / 128), dim3(128), 0, as_stream(stream), stats, (long long)rows, C, eps,
@@ -764,7 +796,7 @@ extern "C" int vfd_bn_act_forward(int dtype, const void* x, void* y, int64_t row
   return VFD_OK;
 }
 
-extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const float* sums, float eps,
+extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_t rows, int C, const double* sums, float eps,
                                        float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
                                        int64_t* num_batches_tracked, const float* gamma, const float* beta, int act, float slope,
                                        void* stream) {
@@ -783,7 +815,7 @@ extern "C" int vfd_bn_act_forward_sums(int dtype, const void* x, void* y, int64_
   return VFD_OK;
 }
 
-extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw, int C, const float* sums,
+extern "C" int vfd_bn_act_pool_forward_sums(int dtype, const void* x, void* y, int N, int D, int H, int W, int pd, int ph, int pw, int C, const double* sums,
                                             float eps, float momentum, float* mean, float* rstd, float* running_mean,
                                             float* running_var, int64_t* num_batches_tracked, const float* gamma, const float* beta,
                                             int act, float slope, void* y_full, void* stream) {

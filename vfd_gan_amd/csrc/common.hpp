@@ -35,7 +35,7 @@ void vfd_set_error(const char* fmt, ...);
   } while (0)
 
 // conv_small.hip: 1 = handled (or, with query, would be handled), 0 = not a thin-channel shape, < 0 = launch error
-int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                        bool query, hipStream_t st);
 
 // Gradient hand-over carried by the epilogue of a data-gradient convolution (conv_epilogue.hpp): the consumer layer's
@@ -57,7 +57,7 @@ struct MulP {
 static inline MulP no_mul() { MulP m; m.src = nullptr; m.act = 0; m.slope = 0.f; m.bn_mean = m.bn_rstd = m.bn_gamma = m.bn_beta = nullptr; m.bn_sums = nullptr; return m; }
 
 // conv_halo.hip: same return convention; unit-input-stride layers with <= 64 output channels (bf16)
-int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                       const MulP& mul, bool query, hipStream_t st);
 
 // conv_wgrad_halo.hip: halo-tiled filter gradient of stride-1 k(1|3)x3x3 layers (bf16); 1 = eligible / launched

@@ -14,7 +14,10 @@
 struct EpiP {
   void* y;
   const float* bias;
-  float* stats;          // [VFD_STATS_REPLICAS][2][Cop] or null
+  double* stats;         // [VFD_STATS_REPLICAS][2][Cop] DOUBLES or null: per-channel sum / sum of squares of (conv + bias) for the
+                         // BatchNorm that follows.  Summed in double from the float32 accumulators on: the variance is later
+                         // formed as E[x^2] - mean^2, which in float32 sums loses |mean|/sigma squared digits (a bias-dominated
+                         // layer on a sparse input - mygan's SDisc on the 0/1 mask - has |mean|/sigma ~ 30: measured 5e-3 on its loss)
   int Cop, Cout;
   int act;
   float slope;
@@ -46,7 +49,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // bf16 tiles of >= 64 channels leave through LDS: the MFMA layout gives a lane 4 channels (8 bytes) of one pixel, i.e.
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
-  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * 4;
+  typedef typename std::conditional<BN, float, double>::type S;      // accumulation type of the per-channel sums (BN hand-over: float)
+  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * (int)sizeof(S);
     // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
   constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
                      : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
@@ -58,7 +62,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
   // same 2*Cout addresses; bn_from_sums folds the replicas).
-  float* red = reinterpret_cast<float*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
+  S* red = reinterpret_cast<S*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
   long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
   long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
   bool pvalid[NJ];
@@ -87,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
         for (int r = 0; r < 4; ++r)
           if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
       }
-      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      S s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
       // BatchNorm hand-over: xh = x * ka + kb, z = xh * kg + kt for this lane's 4 channels; the producer BatchNorm's input
       // x at this lane's (pixel, 4 channels) positions, all loads of the pass in flight before the first use
       float ka[4], kb[4], kg[4], kt[4];
@@ -126,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float t = (SCALED ? acc[i][j][r] * p.oscale : acc[i][j][r]) + b4[r];
-            if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+            if (H == 0 && want_stats && pvalid[j]) { s1[r] += (S)t; s2[r] += (S)t * (S)t; }
             v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
           }
         }
@@ -157,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
       if ((H == 0 || BN) && want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a = s1[r], b = s2[r];
+          S a = s1[r], b = s2[r];
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
           if ((lane & 15) == 0) {
@@ -241,13 +245,15 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     }
   }
   if (want_stats) {
-    float* rep = (BN ? p.mul.bn_sums : p.stats) + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    S* rep;
+    if constexpr (BN) rep = p.mul.bn_sums + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+    else rep = p.stats + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
     for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
       const int which = t / TILE_C, cl = t - which * TILE_C;
-      float v = 0.f;
+      S v = 0;
 #pragma unroll
       for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
-      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);
+      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);      // global_atomic_add_f32 / _f64: one per channel and workgroup
     }
   }
 }

@@ -63,7 +63,7 @@ struct HaloCfg {
   static constexpr int HALO_BYTES = (ROWS_MAX + 15) / 16 * 1024;
   static constexpr int FTAP = TILE_C * 64;                    // one tap's filter slice
   static constexpr int FSTAGE = 3 * FTAP;                     // the (up to 3) w-taps of one (kd, kh)
-  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 4 + 256 * 8;
+  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 8 + 256 * 8;      // output rows + [2][TILE_C][4 waves] double sums + row offsets
   static constexpr int NFS = 2;                               // filter ring depth
   static constexpr int LDS = (HALO_BYTES + NFS * FSTAGE > EPI_BYTES) ? HALO_BYTES + NFS * FSTAGE : EPI_BYTES;
   static constexpr int NHW = ((ROWS_MAX + 15) / 16 + 3) / 4;  // halo DMA instructions per wave (upper bound)
@@ -338,7 +338,7 @@ extern "C" int vfd_conv_set_halo_mode(int mode) {
 }
 
 // 1 = handled (or, with query, would be handled), 0 = not a halo shape, < 0 = launch error
-int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                       const MulP& mul, bool query, hipStream_t st) {
   if (g_halo_mode < 0) g_halo_mode = getenv("VFD_NO_HALO") != nullptr ? 1 : 0;
   if (g_halo_mode == 1 || d->dtype != VFD_BF16) return 0;

@@ -30,7 +30,7 @@ struct ConvP {
   const void* w;
   void* y;
   const float* bias;
-  float* stats;  // [2][Cop] or null
+  double* stats;  // [VFD_STATS_REPLICAS][2][Cop] doubles or null (conv_epilogue.hpp)
   int N, Di, Hi, Wi, Cip;
   int Do, Ho, Wo, Cop, Cout;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
@@ -643,7 +643,7 @@ int vfd_conv_check_desc(const vfd_conv_desc* d) {
   return VFD_OK;
 }
 
-static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, float* stats,
+static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* packed, const float* bias, void* y, double* stats,
                          size_t stats_bytes, void* ws, size_t ws_bytes, size_t* ws_query, void* stream,
                          const MulP& mul = no_mul(), const float* qscale_x = nullptr, const float* qscale_w = nullptr) {
   VFD_REQUIRE(d_in != nullptr, "conv: null descriptor");
@@ -661,8 +661,9 @@ static int conv_dispatch(const vfd_conv_desc* d_in, const void* x, const void* p
   if (rc != VFD_OK) return rc;
   if (ws_query == nullptr) {
     VFD_REQUIRE(x && packed && y, "conv: null tensor pointer");
-    VFD_REQUIRE(stats == nullptr || stats_bytes >= (size_t)VFD_STATS_REPLICAS * 2 * cpad(d->Cout) * sizeof(float),
-                "conv: statistics buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) floats", stats_bytes);
+    VFD_REQUIRE(stats == nullptr || stats_bytes >= (size_t)VFD_STATS_REPLICAS * 2 * cpad(d->Cout) * sizeof(double),
+                "conv: statistics buffer holds %zu bytes, needs VFD_STATS_REPLICAS*2*CPAD(Cout) doubles", stats_bytes);
+    VFD_REQUIRE(((uintptr_t)stats & 7) == 0, "conv: the statistics buffer must be 8-byte aligned");
     VFD_REQUIRE((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y | (uintptr_t)ws) & 15) == 0, "conv: tensors must be 16-byte aligned");
   }
   const bool fp8 = d->dtype == VFD_FP8;      // e4m3 operands, bf16 output: conv_igemm's 128-byte-row tiles only
@@ -744,7 +745,7 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
     snprintf(buf, n, "conv_igemm<fp8,%s>", dn.Cout > 128 ? "256c_x_256p" : "128c_x_128p");
     return VFD_OK;
   }
-  float dummy_stats;
+  double dummy_stats;
   if (vfd_conv_small_try(&dn, nullptr, nullptr, nullptr, nullptr, want_stats != 0 ? &dummy_stats : nullptr, true, nullptr) > 0) {
     const bool pointwise = dn.kh == 1 && dn.kw == 1;      // conv_small.hip: (kd,1,1) filters over 16..64 channels run on conv_cin8
     snprintf(buf, n, "%s<%s>", (cpad(dn.Cin) == 8 || pointwise) ? "conv_cin8" : "convt_thin", t);
@@ -763,12 +764,12 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
 
 extern "C" int vfd_conv_workspace(const vfd_conv_desc* d, int want_stats, size_t* bytes) {
   VFD_REQUIRE(bytes != nullptr, "conv_workspace: null result pointer");
-  float dummy;
+  double dummy;
   return conv_dispatch(d, nullptr, nullptr, nullptr, nullptr, want_stats ? &dummy : nullptr, 0, nullptr, 0, bytes, nullptr);
 }
 
 extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
-                                float* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
+                                double* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream) {
   return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, ws, ws_bytes, nullptr, stream);
 }
 
@@ -776,7 +777,7 @@ extern "C" int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const voi
 // bias), optional BatchNorm statistics; scale_x / scale_w are DEVICE scalars (what the tensors were multiplied by when
 // quantised), read by the kernel, so that a captured step follows scales that change from step to step.
 extern "C" int vfd_conv_forward_fp8(const vfd_conv_desc* d, const void* x, const float* scale_x, const void* packed,
-                                    const float* scale_w, const float* bias, void* y, float* stats, size_t stats_bytes, void* stream) {
+                                    const float* scale_w, const float* bias, void* y, double* stats, size_t stats_bytes, void* stream) {
   VFD_REQUIRE(d != nullptr && d->dtype == VFD_FP8, "conv_forward_fp8: descriptor dtype must be VFD_FP8");
   VFD_REQUIRE(scale_x != nullptr && scale_w != nullptr, "conv_forward_fp8: null scale pointer");
   return conv_dispatch(d, x, packed, bias, y, stats, stats_bytes, nullptr, 0, nullptr, stream, no_mul(), scale_x, scale_w);

@@ -28,7 +28,7 @@ struct Cin8P {
   const bf16_t* w;      // packed [Cout][kd*kh*kw][8]
   bf16_t* y;
   const float* bias;
-  float* stats;         // BatchNorm partial sums [VFD_STATS_REPLICAS][2][Cop] (sum, sum of squares of conv + bias), or null
+  double* stats;        // BatchNorm partial sums [VFD_STATS_REPLICAS][2][Cop] doubles (sum, sum of squares of conv + bias), or null
   int N, Di, Hi, Wi, Do, Ho, Wo, Cout, Cop;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int act;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
   if (tid < 16 * NI_) bias_s[tid] = (p.bias != nullptr && tid < p.Cout) ? p.bias[tid] : 0.f;
   // BatchNorm partial sums of this (persistent) workgroup: accumulated in LDS over all its tiles, ONE global atomic per
   // channel and workgroup at the end
-  float* red_s = bias_s + 16 * NI_;       // [2][16 NI]
-  if (tid < 2 * 16 * NI_) red_s[tid] = 0.f;
+  double* red_s = reinterpret_cast<double*>(bias_s + 16 * NI_);       // [2][16 NI], in double (conv_epilogue.hpp: EpiP::stats)
+  if (tid < 2 * 16 * NI_) red_s[tid] = 0.0;
   __syncthreads();
 
   const int cq = g * 4;
@@ -199,10 +199,10 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
       for (int i = 0; i < NI_; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float a1 = 0.f, a2 = 0.f;
+          double a1 = 0.0, a2 = 0.0;
 #pragma unroll
           for (int j = 0; j < CIN8_NJ; ++j) {
-            const float t = pxok_t[j] ? v[(i * CIN8_NJ + j) * 4 + r] : 0.f;
+            const double t = pxok_t[j] ? (double)v[(i * CIN8_NJ + j) * 4 + r] : 0.0;
             a1 += t; a2 += t * t;
           }
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
     __syncthreads();
     if (tid < 2 * 16 * NI_) {
       const int which = tid / (16 * NI_), c = tid - which * (16 * NI_);
-      float* rep = p.stats + (blockIdx.x % VFD_STATS_REPLICAS) * 2 * p.Cop;      // 32-bit offsets: the buffer is a few KB
+      double* rep = p.stats + (blockIdx.x % VFD_STATS_REPLICAS) * 2 * p.Cop;      // 32-bit offsets: the buffer is a few KB
       if (c < p.Cout) atomicAdd(rep + which * p.Cop + c, red_s[tid]);
     }
   }
@@ -415,10 +415,10 @@ bool small_enabled() {
 }  // namespace
 
 // Returns 1 when the layer was handled (or, with `query`, would be), 0 when it is not one of the two shapes, < 0 on error.
-static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                           bool query, hipStream_t st, int force_flip);
 
-int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                        bool query, hipStream_t st) {
   if (!small_enabled() || d->dtype != VFD_BF16) return 0;
   {
@@ -456,7 +456,7 @@ int vfd_conv_small_try(const vfd_conv_desc* d, const void* x, const void* packed
 
 // force_flip < 0: the tap reversal follows from the descriptor (a stride-1 transposed convolution over <= 8 channels: all
 // three axes); >= 0: the descriptor is already the regular form and force_flip is the tap-reversal mask
-static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, float* stats,
+static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y, double* stats,
                           bool query, hipStream_t st, int force_flip) {
   const int Cip = cpad(d->Cin), Cop = cpad(d->Cout);
   // a stride-1 transposed convolution without output padding is a regular one with reversed taps and pad k-1-p
@@ -485,7 +485,7 @@ static int small_try_impl(const vfd_conv_desc* d, const void* x, const void* pac
     p.M = M;
     p.ntiles = (int)((M + CIN8_TILE - 1) / CIN8_TILE);
     const int ni = d->Cout <= 16 ? 1 : (d->Cout <= 32 ? 2 : 4);
-    const size_t lds = (size_t)d->kd * d->kh * ni * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128 + 3 * 16 * ni * sizeof(float);
+    const size_t lds = (size_t)d->kd * d->kh * ni * 1024 + CIN8_WAVES * CIN8_NJ * 16 * 128 + 16 * ni * sizeof(float) + 2 * 16 * ni * sizeof(double);      // + bias + double sums
     const int blocks = p.ntiles < 1024 ? p.ntiles : 1024;
     const int rows = d->kd * d->kh;
     const int rsel = (rows == 1 || rows == 3 || rows == 4 || rows == 9) ? rows : 0;

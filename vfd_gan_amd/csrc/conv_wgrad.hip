@@ -267,14 +267,22 @@ __global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad
 // the parameter's gradient db[Cb] (vfd_bn_backward_apply_sums; a separate fold launch would cost as much as it does).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int A, int B,
                                                            int T, int Bp, int nsplit, float beta, long long wblocks,
-                                                           const float* __restrict__ bias_rep, float* __restrict__ db, int Cb, int rep_stride) {
+                                                           const void* __restrict__ bias_rep, float* __restrict__ db, int Cb, int rep_stride,
+                                                           int rep_f64) {
   if ((long long)blockIdx.x >= wblocks) {
     const int c = (int)(blockIdx.x - wblocks) * 256 + threadIdx.x;
     if (c < Cb) {
-      float v = 0.f;
+      if (rep_f64) {      // rows of a conv epilogue's statistics buffer (doubles, conv_epilogue.hpp)
+        double v = 0.0;
 #pragma unroll
-      for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += bias_rep[(size_t)r * rep_stride + c];
-      db[c] += v;
+        for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += reinterpret_cast<const double*>(bias_rep)[(size_t)r * rep_stride + c];
+        db[c] += (float)v;
+      } else {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < VFD_STATS_REPLICAS; ++r) v += reinterpret_cast<const float*>(bias_rep)[(size_t)r * rep_stride + c];
+        db[c] += v;
+      }
     }
     return;
   }
@@ -451,8 +459,8 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   return VFD_OK;
 }
 
-static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep, float* db,
-                               int rep_stride, void* stream) {
+static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const void* bias_rep, float* db,
+                               int rep_stride, int rep_f64, void* stream) {
   WgGeom g;
   int rc = make_geom(d, g);
   if (rc != VFD_OK) return rc;
@@ -462,18 +470,18 @@ static int wgrad_reduce_launch(const vfd_conv_desc* d, const void* ws, float* dw
   const int extra = bias_rep != nullptr ? (d->Cout + 255) / 256 : 0;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks + extra)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float*>(ws), dw, g.A, g.B, g.T, g.p.Cgp, g.nsplit, beta, blocks, bias_rep, db, d->Cout,
-                     rep_stride);
+                     rep_stride, rep_f64);
   VFD_CHECK_LAUNCH("wgrad_reduce");
   return VFD_OK;
 }
 
 extern "C" int vfd_wgrad_reduce(const vfd_conv_desc* d, const void* ws, float* dw, float beta, void* stream) {
-  return wgrad_reduce_launch(d, ws, dw, beta, nullptr, nullptr, 0, stream);
+  return wgrad_reduce_launch(d, ws, dw, beta, nullptr, nullptr, 0, 0, stream);
 }
 
-extern "C" int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const float* bias_rep,
-                                     int rep_stride, float* db, void* stream) {
+extern "C" int vfd_wgrad_reduce_bias(const vfd_conv_desc* d, const void* ws, float* dw, float beta, const void* bias_rep,
+                                     int rep_stride, int rep_f64, float* db, void* stream) {
   VFD_REQUIRE(d && bias_rep && db, "wgrad_reduce_bias: null pointer");
   VFD_REQUIRE(rep_stride >= cpad(d->Cout), "wgrad_reduce_bias: replica rows of %d floats are shorter than CPAD(Cout)", rep_stride);
-  return wgrad_reduce_launch(d, ws, dw, beta, bias_rep, db, rep_stride, stream);
+  return wgrad_reduce_launch(d, ws, dw, beta, bias_rep, db, rep_stride, rep_f64 != 0, stream);
 }

@@ -121,13 +121,25 @@ def join_side_stream():
 
 
 def stats_buffer_numel(C):
-    """Floats in the conv-epilogue statistics buffer of a C-channel output (see new_stats_buffer)."""
+    """Elements of a [STATS_REPLICAS][2][CPAD(C)] sums buffer: float64 for a conv epilogue's forward statistics
+    (new_stats_buffer), float32 for the BatchNorm backward sums / bias-gradient rows."""
     return STATS_REPLICAS * 2 * cpad(C)
 
 
 def new_stats_buffer(channels, device):
-    """Zeroed [STATS_REPLICAS][2][CPAD(C)] float32 buffer for a conv epilogue's BatchNorm partial sums."""
-    return torch.zeros(STATS_REPLICAS * 2 * cpad(channels), dtype=torch.float32, device=device)
+    """Zeroed [STATS_REPLICAS][2][CPAD(C)] FLOAT64 buffer for a conv epilogue's BatchNorm partial sums (the kernels add up
+    their float32 accumulators in double: include/vfdgan_hip.h, vfd_conv_forward)."""
+    return torch.zeros(STATS_REPLICAS * 2 * cpad(channels), dtype=torch.float64, device=device)
+
+
+def _stats_arg(stats):
+    """(pointer, bytes) of a conv-epilogue statistics buffer; float64 is part of the contract (a float32 buffer of the right
+    byte size would be half as many elements as the kernel writes)."""
+    if stats is None:
+        return 0, 0
+    if stats.dtype != torch.float64:
+        raise TypeError("conv epilogue statistics are float64 (functional.new_stats_buffer), got %s" % stats.dtype)
+    return stats.data_ptr(), stats.numel() * 8
 
 
 class ClTensor:
@@ -490,7 +502,7 @@ def _conv_launch(desc, x, packed, bias, out, stats=None, mul=None, bn=None):
         check(lib.vfd_conv_workspace(ctypes.byref(desc), int(stats is not None), ctypes.byref(need)), "conv_workspace")
         ws = _workspace(need.value, x.device) if need.value else None
         check(lib.vfd_conv_forward(ctypes.byref(desc), x.data_ptr(), packed.data_ptr(), ptr(bias), out.data_ptr(),
-                                   ptr(stats), stats.numel() * 4 if stats is not None else 0, ptr(ws), need.value, stream()),
+                                   *_stats_arg(stats), ptr(ws), need.value, stream()),
               "conv_forward")
     if timer is not None:
         e1.record()
@@ -621,7 +633,8 @@ class _Conv(torch.autograd.Function):
                     # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias
                     # gradient) in replica rows: folded by the same launch
                     check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
-                                                    int(tok.get("stride", cpad(Cout))), bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
+                                                    int(tok.get("stride", cpad(Cout))), int(tok["rep"].dtype == torch.float64),
+                                                    bdirect.data_ptr(), stream()), "wgrad_reduce_bias")
                     bias_done = True
                 elif direct is not None:
                     check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, stream()), "wgrad_reduce")
@@ -760,7 +773,7 @@ def conv_fp8(xq, xscale, wq, wscale, bias, N, in_dhw, Cin, out_dhw, Cout, k, s, 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(load().vfd_conv_forward_fp8(ctypes.byref(desc), xq.data_ptr(), xscale.data_ptr(), wq.data_ptr(), wscale.data_ptr(), ptr(bias),
-                                      y.data_ptr(), ptr(stats), stats.numel() * 4 if stats is not None else 0, stream()), "conv_forward_fp8")
+                                      y.data_ptr(), *_stats_arg(stats), stream()), "conv_forward_fp8")
     if timer is not None:
         e1.record()
         timer.records.append((_conv_kernel_name(desc, stats), _conv_flops(desc), e0, e1, _geom_str(desc, stats)))
@@ -822,8 +835,8 @@ class _BnAct(torch.autograd.Function):
         g_, b_ = (gamma.detach() if gamma is not None else None), (beta.detach() if beta is not None else None)
         if sums is not None:
             # statistics handed over by the producing conv's epilogue: fold + normalise + activate in one launch
-            if sums.numel() < STATS_REPLICAS * 2 * cpad(C):
-                raise RuntimeError("bn_act: statistics buffer too small (use functional.new_stats_buffer)")
+            if sums.numel() < STATS_REPLICAS * 2 * cpad(C) or sums.dtype != torch.float64:
+                raise RuntimeError("bn_act: statistics buffer too small or not float64 (use functional.new_stats_buffer)")
             check(lib.vfd_bn_act_forward_sums(dtc, x.data_ptr(), y.data_ptr(), rows, C, sums.data_ptr(), eps, momentum,
                                               mean.data_ptr(), rstd.data_ptr(), ptr(running_mean), ptr(running_var), ptr(nbt),
                                               ptr(g_), ptr(b_), act, slope, stream()), "bn_act_forward_sums")

@@ -31,15 +31,16 @@ def _conv_bn_act(block, x, slope, pool=None, keep_full=False):
     (pooled, full) is returned): absorbed into the BatchNorm pass where it can be (functional._BnActPool)."""
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
-        buf = torch.zeros(3 * k, dtype=torch.float32, device=x.t.device)      # forward statistics | backward sums | bias sums: one fill
+        buf = torch.zeros(4 * k, dtype=torch.float32, device=x.t.device)      # forward statistics (float64) | backward sums | bias sums: one fill
+        fstats, bsums, brep = buf[:2 * k].view(torch.float64), buf[2 * k:3 * k], buf[3 * k:]
         tbias = block.conv.temporal_conv.bias
-        tok = {"taken": False, "rep": buf[2 * k:]} if tbias is not None else None
-        x = block.conv(x, stats=buf[:k], bias_token=tok)
+        tok = {"taken": False, "rep": brep} if tbias is not None else None
+        x = block.conv(x, stats=fstats, bias_token=tok)
         if pool is not None and not hnn._NO_HANDOVER and block.bn.momentum is not None:
             pks = F.pool_fusable(pool.kernel_size, pool.stride, pool.padding, tuple(x.t.shape[1:4]))
             if pks is not None:
-                return block.bn.forward_pooled(x, _lib.ACT_LRELU, slope, buf[:k], buf[k:2 * k], tbias, tok, pks, keep_full)
-        x = block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=buf[:k], bwd_sums=buf[k:2 * k], conv_bias=tbias, bias_token=tok)
+                return block.bn.forward_pooled(x, _lib.ACT_LRELU, slope, fstats, bsums, tbias, tok, pks, keep_full)
+        x = block.bn(x, act=_lib.ACT_LRELU, slope=slope, sums=fstats, bwd_sums=bsums, conv_bias=tbias, bias_token=tok)
     else:
         x = block.bn(block.conv(x), act=_lib.ACT_LRELU, slope=slope)
     if pool is None:

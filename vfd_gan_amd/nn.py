@@ -237,26 +237,37 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
         return j + 2 if (j + 1 < n and _act_of(mods[j + 1]) is not None) else j + 1
 
     # one zero-filled allocation for every sum buffer of the list (one fill launch): forward statistics of each
-    # conv -> BatchNorm pair, backward sums of each BatchNorm
-    pool, pool_off = None, 0
+    # conv -> BatchNorm pair (float64: the conv epilogues sum in double), backward sums of each BatchNorm (float32)
+    pool, pool64, pool_off, pool64_off = None, None, 0, 0
     if epi:
-        need = 0
+        need = need64 = 0
         for j, m in enumerate(mods):
             if isinstance(m, _BNS) and m.training:
                 if j > 0 and is_conv(j - 1):
-                    need += F.stats_buffer_numel(m.num_features) * (2 if mods[j - 1].bias is not None else 1)
+                    need64 += F.stats_buffer_numel(m.num_features)      # forward statistics from the conv epilogue
+                    if mods[j - 1].bias is not None:
+                        need += F.stats_buffer_numel(m.num_features)    # the conv's bias gradient, left by this BatchNorm's apply pass
                 need += F.stats_buffer_numel(m.num_features)      # backward sums (every training BatchNorm)
             if handover and is_conv(j) and m.bias is not None and is_conv(j + 1):
-                need += F.stats_buffer_numel(m.out_channels)      # conv(bias) -> conv: the first one's bias gradient
-        if need:
-            pool = torch.zeros(need, dtype=torch.float32, device=x.t.device)
+                need64 += F.stats_buffer_numel(m.out_channels)      # conv(bias) -> conv: the first one's bias gradient (epilogue sums of the second's data gradient)
+        if need or need64:
+            pool = torch.zeros(need + 2 * need64, dtype=torch.float32, device=x.t.device)
             F.register_pool(pool)
+            pool64 = pool[:2 * need64].view(torch.float64)      # the float64 part first (8-byte aligned: start of the allocation)
+            pool_off = 2 * need64
 
     def take(C):
         nonlocal pool_off
         k = F.stats_buffer_numel(C)
         buf = pool.narrow(0, pool_off, k)
         pool_off += k
+        return buf
+
+    def take64(C):
+        nonlocal pool64_off
+        k = F.stats_buffer_numel(C)
+        buf = pool64.narrow(0, pool64_off, k)
+        pool64_off += k
         return buf
 
     def pool2_after(j, in_dhw):
@@ -304,7 +315,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
             if handover and pool is not None and is_conv(i) and m.bias is not None and is_conv(i + 1):
                 # conv(bias) -> conv with nothing in between: the consumer's data-gradient launch takes the column sums of
                 # its output (this layer's bias gradient) as epilogue statistics
-                chain_tok = {"taken": False, "rep": take(m.out_channels), "stride": 2 * F.cpad(m.out_channels)}
+                chain_tok = {"taken": False, "rep": take64(m.out_channels), "stride": 2 * F.cpad(m.out_channels)}
                 kw["bias_token"] = chain_tok
             a = _act_of(nxt) if nxt is not None else None
             if a is not None:
@@ -313,7 +324,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
                 i += 2
                 continue
             if isinstance(nxt, _BNS) and not isinstance(m, Linear) and nxt.training and epi:
-                sums = take(m.out_channels)
+                sums = take64(m.out_channels)
                 tok = {"taken": False, "rep": take(m.out_channels)} if m.bias is not None else None
                 if tok is not None:
                     kw["bias_token"] = tok
