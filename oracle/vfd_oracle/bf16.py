@@ -38,8 +38,6 @@ from . import mygannet as OM
 from .spatiotempconv import SpatioTemporalConv
 
 KNOWN_MISMATCHES = (
-    "a tensor with several consumers (ganomaly's fake: L1 loss, encoder2, netD) sums its incoming gradients in float32 here "
-    "and rounds once; the HIP path stores each contribution in bf16 before they are added",
     "float32 summation order (MFMA K order, atomics) differs from torch's: a value within ~1e-6 relative of a bf16 rounding "
     "boundary may round the other way (~0.001 % of a conv's outputs)",
 )
@@ -74,6 +72,53 @@ def RF(x):
 def RB(x):
     """Stored backward only (the gradient w.r.t. a value that never leaves the registers forward)."""
     return _Round.apply(x, False, True)
+
+
+class _ActFromOutput(torch.autograd.Function):
+    """y = bf16(act(t)) as a conv + activation kernel stores it, with the derivative taken from the STORED output, as
+    vfd_act_backward / the `mul` epilogue do (csrc/common.hpp act_grad_from_out): LeakyReLU by the sign of y, sigmoid y(1-y),
+    tanh 1-y^2 — near saturation 1-y^2 of a bf16-rounded y differs from the exact derivative by tens of percent, which is the
+    HIP path's arithmetic, not an error of it.  round_g: the incoming gradient is a stored tensor (no consumer claimed it)."""
+
+    @staticmethod
+    def forward(ctx, t, kind, slope, round_g):
+        if kind == "lrelu":
+            y = torch.where(t > 0, t, t * slope)
+        elif kind == "sigmoid":
+            y = torch.sigmoid(t)
+        else:
+            y = torch.tanh(t)
+        y = rbf(y)
+        ctx.save_for_backward(y)
+        ctx.meta = (kind, slope, round_g)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        kind, slope, round_g = ctx.meta
+        if round_g:
+            g = rbf(g)
+        if kind == "lrelu":
+            d = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+        elif kind == "sigmoid":
+            d = y * (1 - y)
+        else:
+            d = 1 - y * y
+        return g * d, None, None, None
+
+
+def act_from_output(act, t, round_g):
+    """The activation module `act` applied in a conv epilogue (see _ActFromOutput)."""
+    if isinstance(act, nn.LeakyReLU):
+        return _ActFromOutput.apply(t, "lrelu", float(act.negative_slope), round_g)
+    if isinstance(act, nn.ReLU):
+        return _ActFromOutput.apply(t, "lrelu", 0.0, round_g)
+    if isinstance(act, nn.Sigmoid):
+        return _ActFromOutput.apply(t, "sigmoid", 0.0, round_g)
+    if isinstance(act, nn.Tanh):
+        return _ActFromOutput.apply(t, "tanh", 0.0, round_g)
+    raise NotImplementedError(type(act).__name__)
 
 
 def wq(w):
@@ -202,8 +247,7 @@ def run_seq(mods, x, return_last_t=False):
                 # consumer's data-gradient kernel unless that kernel applies act' in its own epilogue (the next conv of the
                 # same list claims it: nn.run_fused `claim_act_grad`)
                 claimed = not isinstance(m, nn.Linear) and is_conv(i + 2)
-                y = nxt(RB(conv_q(m, x)))
-                x = RF(y) if claimed else R(y)
+                x = act_from_output(nxt, RB(conv_q(m, x)), round_g=not claimed)
                 i += 2
                 continue
             t = conv_q(m, x)
@@ -220,7 +264,9 @@ def run_seq(mods, x, return_last_t=False):
             continue
         if isinstance(m, nn.Dropout):
             x = R(m(x)) if (m.training and m.p > 0) else x
-        elif isinstance(m, (nn.AvgPool3d, nn.Upsample) + _ACTS):
+        elif isinstance(m, _ACTS):
+            x = act_from_output(m, RB(x), round_g=True)      # a pass of its own (vfd_act_forward / vfd_act_backward: derivative from y)
+        elif isinstance(m, (nn.AvgPool3d, nn.Upsample)):
             x = R(m(x))
         else:
             raise NotImplementedError("bf16-faithful plan for %s" % type(m).__name__)

@@ -117,8 +117,11 @@ __device__ uint4 g_wg_zero_page[4];   // source of every masked 16-byte chunk (s
 // WR x WC waves of 64 x 64 outputs each: tile = 64*WR channels of S x 64*WC flattened columns of G.
 // 2 x 2 (4 waves, 3 workgroups per CU) for narrow layers, 1 x 4 (64 x 256) when S has <= 64 channels; 4 x 2 (8 waves, 2 per CU) where S has >= 256 channels and
 // 2 x 4 where it has 65..128: 24 KiB of DMA per 32-pixel step instead of 16 KiB for twice the MFMA work.
+// 4 x 4 (16 waves, ONE workgroup per CU, 256 x 256: round 3): 32 KiB of DMA per 32-pixel step for 1024 MFMA cycles per SIMD =
+// 31 B/clk/CU, against 47 B/clk/CU for 4 x 2 — the same step that took conv_igemm's 256-channel tile off the DMA ceiling.
+// (launch bound: the 64 x 256 tile's 4 waves need ~140 registers, i.e. 2 workgroups' worth per SIMD, not 3)
 template <typename T, int STAGES, int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? 3 : 4) void conv_wgrad_kernel(const WgP p) {
+__global__ __launch_bounds__(64 * WR * WC, WR * WC == 4 ? (WR == 1 ? 2 : 3) : 4) void conv_wgrad_kernel(const WgP p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KP = WgTraits<T>::KP;
   constexpr int NW = WR * WC;                 // waves
@@ -365,13 +368,14 @@ int make_geom(const vfd_conv_desc* d, WgGeom& g) {
   VFD_REQUIRE(p.M < 0x7fffffffLL, "wgrad: pixel count %lld exceeds 2^31", p.M);
   const int KP = d->dtype == VFD_BF16 ? 32 : 16;
   static const int force_tile = getenv("VFD_WGRAD_TILE") ? atoi(getenv("VFD_WGRAD_TILE")) : 0;   // tuning: 1 = 128x128, 2 = 256x128, 3 = 128x256
-  // 4 = 64x256 (4 waves): S with <= 64 channels would leave half of a 128-row tile empty
-  const int shape = force_tile ? force_tile : (p.Cs >= 256 ? 2 : (p.ncols >= 256 ? (p.Cs > 64 ? 3 : 4) : 1));
+  // 4 = 64x256 (4 waves): S with <= 64 channels would leave half of a 128-row tile empty; 5 = 256x256 (16 waves, bf16)
+  int shape = force_tile ? force_tile : (p.Cs >= 256 ? ((d->dtype == VFD_BF16 && p.ncols >= 256) ? 5 : 2) : (p.ncols >= 256 ? (p.Cs > 64 ? 3 : 4) : 1));
+  if (shape == 5 && d->dtype != VFD_BF16) shape = 2;
   const bool wide = shape == 2 || shape == 3;
-  g.tr = shape == 2 ? 256 : (shape == 4 ? 64 : 128);
-  g.tc = (shape == 3 || shape == 4) ? 256 : 128;
+  g.tr = (shape == 2 || shape == 5) ? 256 : (shape == 4 ? 64 : 128);
+  g.tc = (shape == 3 || shape == 4 || shape == 5) ? 256 : 128;
   const long long tiles = (long long)((p.Cs + g.tr - 1) / g.tr) * ((p.ncols + g.tc - 1) / g.tc);
-  long long nsplit = (wide ? 512 : 768) / tiles;   // one round of 2 (8 waves) or 3 (4 waves) resident workgroups per CU
+  long long nsplit = (shape == 5 ? 256 : (wide ? 512 : 768)) / tiles;   // one round of 1 (16 waves), 2 (8 waves) or 3 (4 waves) resident workgroups per CU
   const long long maxsplit = (p.M + 4 * KP - 1) / (4 * KP);
   if (nsplit > maxsplit) nsplit = maxsplit;
   if (nsplit > 1024) nsplit = 1024;
@@ -445,7 +449,10 @@ extern "C" int vfd_conv_wgrad(const vfd_conv_desc* d, const void* x, const void*
   dim3 grid((unsigned)nwg, 1, 1);
   hipStream_t st = as_stream(stream);
   if (d->dtype == VFD_BF16) {
-    if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
+    static const int st4 = getenv("VFD_WGRAD_STAGES") ? atoi(getenv("VFD_WGRAD_STAGES")) : 3;      // tuning (A/B of the ring depth)
+    if (g.tr == 256 && g.tc == 256 && st4 == 4) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 4, 4, 4>), grid, dim3(1024), 0, st, g.p);
+    else if (g.tr == 256 && g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 4>), grid, dim3(1024), 0, st, g.p);
+    else if (g.tr == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 4, 2>), grid, dim3(512), 0, st, g.p);
     else if (g.tr == 64) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 1, 4>), grid, dim3(256), 0, st, g.p);
     else if (g.tc == 256) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 4>), grid, dim3(512), 0, st, g.p);
     else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, 2, 2>), grid, dim3(256), 0, st, g.p);

@@ -75,7 +75,11 @@ class GraphedStep:
                     # fails while the capture is open, and RCCL's watchdog thread polls the events of earlier collectives
                     # (hipEventQuery) whenever it likes — found by the single-rank RCCL test (mygan, graph mode: "operation
                     # not permitted when stream is capturing" raised inside ProcessGroupNCCL's watchdog, process aborted)
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    # stream=s: the capture runs on the stream the warm-up steps ran on, so that autograd's leaf-gradient
+                    # accumulation (AccumulateGrad remembers the stream of a gradient's first accumulation) needs no
+                    # cross-stream wait inside the capture (the "AccumulateGrad stream mismatch ... may break CUDA graph
+                    # capture" warning of rounds 1-2, and the mechanism behind round 1's capture_end fault)
+                    with torch.cuda.graph(g, pool=pool, stream=s, capture_error_mode="thread_local"):
                         obj()
                         F.join_side_stream()      # a side stream forked inside the capture must rejoin before it ends
                     pool = g.pool()        # later phases read tensors the earlier ones allocated: share one pool

@@ -126,7 +126,10 @@ class GANBaseModel():
             self.global_step = int(o_ck.get('global_step', 0))
             if 'dropout' in o_ck:
                 F.set_dropout_state(o_ck['dropout'], self.device)
-            if 'device_rng' in o_ck:
+            if 'device_rng' in o_ck and self.world_size == 1:
+                # (the file holds RANK 0's generator state: under data parallelism every rank keeps the rank-offset seed its
+                # constructor set, so that replicas go on drawing DIFFERENT noise — SURVEY.md 8e; the bit-identical continuation
+                # of tests/test_trainer_resume.py is a one-rank property)
                 torch.cuda.set_rng_state(o_ck['device_rng'].cpu(), self.device)
         if self.rank == 0:
             print("\n Done.\n")

@@ -92,7 +92,7 @@ class VFD_STCNN():
         self.errors_dict.update({'loss/err/train': self.err})
 
     def errors(self):
-        return {k: float(v) for k, v in self.errors_dict.items()}
+        return {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in self.errors_dict.items()}
 
     def train(self):
         for self.epoch in range(self.args.ep):

@@ -154,7 +154,10 @@ class NetG(tnn.Module):
         xc = F.to_cl(x) if plain else x
         latent_i = self.encoder1(xc)
         gen_imag = self.decoder(latent_i)
-        latent_o = self.encoder2(gen_imag)
+        # gen_imag has THREE consumers in the training step (encoder2 here, the L1 term and netD in Ganomaly): three handles whose
+        # gradients are summed by one launch in float32 (functional.fanout) instead of autograd's two bf16 add kernels
+        gen_enc, gen_imag, self._gen_for_d = F.fanout(gen_imag, 3)
+        latent_o = self.encoder2(gen_enc)
         if plain:
             return gen_imag.to_torch(), latent_i.to_torch(), latent_o.to_torch()
         return gen_imag, latent_i, latent_o
@@ -222,6 +225,7 @@ class Ganomaly(GANBaseModel):
 
     def forward_g(self):
         self.fake, self.latent_i, self.latent_o = self.netg(self.x)
+        self.fake_d = self.netg._gen_for_d          # netD's handle of the generated frames (see NetG.forward)
 
     def forward_d(self):
         """netd(input) and netd(fake), ONCE each.  The reference evaluates both a second time inside backward_g
@@ -235,7 +239,7 @@ class Ganomaly(GANBaseModel):
         self.pred_real, self.feat_real = self.netd(self.x)
         stats_real = [(m, m._batch_stats) for m in bns if m.training]
         with F.collect_pools() as self._dfake_pools:
-            self.pred_fake, self.feat_fake = self.netd(self.fake)
+            self.pred_fake, self.feat_fake = self.netd(self.fake_d)
         stats_fake = [(m, m._batch_stats) for m in bns if m.training]
         for m in bns:
             m._keep_batch_stats = False
@@ -274,7 +278,7 @@ class Ganomaly(GANBaseModel):
         self.err_d = (self.err_d_real + self.err_d_fake) * 0.5
         for pool in self._dfake_pools:          # BatchNorm / bias sum buffers of netd(fake): second walk of that graph
             pool.zero_()
-        skip = self.fake.t.data_ptr()           # ... which stops at netD's first layer (the reference detaches fake here)
+        skip = self.fake_d.t.data_ptr()         # ... which stops at netD's first layer (the reference detaches fake here)
         F._SKIP_INPUT_GRAD.add(skip)
         try:
             torch.autograd.backward(self.err_d, inputs=[p for p in self.netd.parameters() if p.requires_grad])
