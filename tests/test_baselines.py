@@ -46,9 +46,14 @@ def test_baseline_step_reference_geometry_golden(name, dt, dev, tmp_path):
     tr.set_input((inp, inp, gt, torch.ones(1, 16)))
     tr.optimize_params()
     f32 = dt == torch.float32
-    check_errs({"err": tr.errors()["loss/err/train"]}, R["step_p0"]["errs"], 1e-4 if f32 else 3e-2, name)
+    # Xception is 12 residual blocks of [ReLU, conv, ReLU, conv, ReLU, BatchNorm over 1024 samples] x 3: float32 rounding noise
+    # doubles per block (tools/probe/xception_stages.py: 2e-6 after block 1, 1.6e-2 max-norm after block 12, HIP vs oracle), and
+    # the REFERENCE's own loss moves by 1e-5 .. 9e-5 when its input is perturbed by one float32 ulp (measured on the oracle):
+    # its loss is gated at 5e-4, its prediction at 3e-2; the auto-encoder (8 blocks, no such chain) at the usual 1e-4 / 1e-3
+    ltol, ptol = ((1e-4, 1e-3) if name == "autoencoder" else (5e-4, 3e-2)) if f32 else (3e-2, None)
+    check_errs({"err": tr.errors()["loss/err/train"]}, R["step_p0"]["errs"], ltol, name)
     if f32:
-        check_summary(tr.predict.to_torch(), R["step_p0"]["predict"], 1e-3, name + " predict")
+        check_summary(tr.predict.to_torch(), R["step_p0"]["predict"], ptol, name + " predict")
         sd = tr.model.state_dict()
         for k, ref in R["after1"].items():
             if "running" in k:

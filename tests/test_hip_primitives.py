@@ -783,3 +783,62 @@ def test_conv_to_conv_bias_gradient_from_data_gradient_statistics(dev):
         e = relrms(pm.grad, pr.grad)
         assert e < 0.06, (n, e)
     assert relerr(mine[0].bias.grad, ref[0].bias.grad) < tol and relerr(mine[1].bias.grad, ref[1].bias.grad) < tol
+
+
+@pytest.mark.parametrize("dt,ratio", [(torch.float32, 1000.0), (torch.bfloat16, 30.0)], ids=["f32_1e3", "bf16_30"])
+def test_batchnorm_epilogue_statistics_large_mean_over_sigma(dt, ratio, dev):
+    """|mean| / sigma >> 1 on the conv-epilogue-sums path: conv(bias = ratio * sigma) ->
+    BatchNorm -> LeakyReLU with the statistics summed in the conv epilogue.  The variance is E[x^2] - mean^2: float32 sums
+    lose ratio^2 digits there (at 1e3 nothing is left; mygan's SDisc on the sparse 0/1 mask sits at ~30 and was off by 5e-3 in
+    its loss), so the epilogues sum in DOUBLE (include/vfdgan_hip.h vfd_conv_forward).  Checked against float64 BatchNorm of
+    the stored conv output: running variance, forward, and the backward's re-associated apply pass (dx = g A + x B + D).
+    (bf16 storage itself resolves a tensor only to 2^-9 |mean|: a ratio of 30 leaves sigma / 17 of rounding noise in x.)"""
+    import vfd_gan_amd.nn as vnn
+    from vfd_gan_amd import functional as F
+    torch.manual_seed(3)
+    N, Ci, Co, sp = 4, 8, 16, (4, 12, 12)
+    x = _rand((N, Ci) + sp, 41)
+    w = _rand((Co, Ci, 1, 1, 1), 42, 0.3)
+    sigma = float(TF.conv3d(x, w).std())
+    b = torch.full((Co,), ratio * sigma) * (1 + 0.1 * _rand((Co,), 43))
+    if dt == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    conv, bn, act = vnn.Conv3d(Ci, Co, 1, 1, 0), vnn.BatchNorm3d(Co), vnn.LeakyReLU(0.2)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        conv.bias.copy_(b)
+        bn.weight.copy_(1 + 0.2 * _rand((Co,), 44))
+        bn.bias.copy_(_rand((Co,), 45))
+    seq = vnn.Sequential(conv, bn, act).to(dev).train()
+    vnn.set_epilogue_stats("on")
+    try:
+        xd = x.to(dev).requires_grad_()
+        yc = seq(F.to_cl(xd, dt))
+        y = yc.to_torch()
+        gy = _rand(tuple(y.shape), 46)
+        y.backward(gy.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        vnn.set_epilogue_stats("auto")
+    # float64 reference on the conv output AS STORED (float32 / bf16 rounding of the conv output is not what is tested)
+    t = TF.conv3d(x.double(), w.double(), b.double())
+    ts = (t.float() if dt == torch.float32 else t.float().bfloat16().float()).double().requires_grad_()
+    mean, var = t.mean((0, 2, 3, 4)), t.var((0, 2, 3, 4), unbiased=False)       # statistics of the unrounded accumulators
+    sh = (1, -1, 1, 1, 1)
+    xh = (ts - mean.view(sh)) / torch.sqrt(var.view(sh) + bn.eps)
+    yr = TF.leaky_relu(xh * bn.weight.detach().cpu().double().view(sh) + bn.bias.detach().cpu().double().view(sh), 0.2)
+    n = t.numel() // Co
+    assert relerr(bn.running_var.cpu(), (0.9 + 0.1 * var * n / (n - 1)).float()) < 1e-4      # 1 - momentum, momentum * unbiased variance
+    assert relerr(bn.running_mean.cpu(), (0.1 * mean).float()) < 1e-5
+    tol = 2e-4 if dt == torch.float32 else 4e-2
+    assert relerr(y, yr.float()) < tol, relerr(y, yr.float())
+    # backward through the BatchNorm (statistics as functions of the data: the standard formula on the stored tensor)
+    g = gy.double() * torch.where(yr > 0, 1.0, 0.2)
+    gam = bn.weight.detach().cpu().double().view(sh)
+    rstd = 1.0 / torch.sqrt(var.view(sh) + bn.eps)
+    dxh = g * gam
+    dt_ref = rstd * (dxh - dxh.mean((0, 2, 3, 4), keepdim=True) - xh.detach() * (dxh * xh.detach()).mean((0, 2, 3, 4), keepdim=True))
+    dx_ref = TF.conv_transpose3d(dt_ref, w.double())          # back through the 1x1x1 conv
+    assert relrms(xd.grad, dx_ref.float()) < (1e-3 if dt == torch.float32 else 5e-2), relrms(xd.grad, dx_ref.float())
+    assert relerr(bn.weight.grad.cpu(), (g * xh.detach()).sum((0, 2, 3, 4)).float()) < (1e-3 if dt == torch.float32 else 5e-2)
+    assert relerr(bn.bias.grad.cpu(), g.sum((0, 2, 3, 4)).float()) < (1e-4 if dt == torch.float32 else 2e-2)

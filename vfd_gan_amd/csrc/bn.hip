@@ -598,10 +598,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
     if (colsum_acc != nullptr) { __syncthreads(); __syncthreads(); }      // the two barriers of the column-sum fold at the end
     return;
   }
-  // dx = gamma*rstd*(g - mean(g) - xh*mean(g*xh)) with xh = (x - mu)*rstd, re-associated into dx = g*A + x*B + D, and
-  // z = gamma*xh + beta = x*E + F for the activation derivative: 5 constants per channel instead of 7 (this kernel
-  // streams 4 rows x 2 tensors per thread; at 7 it needed 188 registers, i.e. 2 waves per SIMD)
-  float A[8], B[8], D[8], E[8], Fz[8], cs[8];
+  // dx = gamma*rstd*(g - mean(g) - xh*mean(g*xh)) with xh = (x - mu)*rstd, re-associated into dx = g*A + xc*B + D with
+  // xc = x - mu, and z = gamma*xh + beta = xc*A + beta for the activation derivative: 5 constants per channel instead of
+  // 7 (this kernel streams 4 rows x 2 tensors per thread; at 7 it needed 188 registers, i.e. 2 waves per SIMD).  The mean
+  // is subtracted FIRST: round 2's x*B + D (D carrying mu*B) cancelled |mean|/sigma digits (8.6e-3 on dx at a ratio of 1e3,
+  // tests/test_hip_primitives.py::test_batchnorm_epilogue_statistics_large_mean_over_sigma).
+  float A[8], B[8], D[8], Mu[8], Be[8], cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
   const float inv = 1.f / ((float)rows * (POOL ? (float)(pa.pd * pa.ph * pa.pw) : 1.f));      // means are over the INPUT rows
@@ -615,11 +617,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
       const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f;
       const float ga = ok ? (gamma ? gamma[c] : 1.f) : 0.f, be = (ok && beta) ? beta[c] : 0.f;
       const float gr = ga * rs, c1 = ok ? sg * inv : 0.f, c2 = ok ? sgx * inv : 0.f;
-      A[k] = gr;
+      A[k] = gr;                 // = gamma * rstd: also the slope of z in xc
       B[k] = -rs * gr * c2;
-      D[k] = -gr * c1 + mu * rs * gr * c2;
-      E[k] = rs * ga;
-      Fz[k] = be - mu * rs * ga;
+      D[k] = -gr * c1;
+      Mu[k] = mu;
+      Be[k] = be;
       if (ok && publish) {
         dbeta[c] = sg;
         dgamma[c] = sgx;
@@ -650,8 +652,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             float gzv = gp[k] * inv_q + (gfull != nullptr ? gf[k] : 0.f);
-            if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[q][k] * E[k] + Fz[k], slope);
-            o[k] = gzv * A[k] + (v[q][k] * B[k] + D[k]);
+            const float xc = v[q][k] - Mu[k];
+            if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(xc * A[k] + Be[k], slope);
+            o[k] = gzv * A[k] + (xc * B[k] + D[k]);
             cs[k] += o[k];
           }
           store8(dx + (b0 + pool_off(q, pa)) * Cp + g * 8, o);
@@ -674,7 +677,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_sums_kernel(const T* __restr
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float gzv = d[u][k];
-        if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[u][k] * E[k] + Fz[k], slope);
+        v[u][k] -= Mu[k];
+        if constexpr (ACT >= 0) gzv *= act_grad_in_c<ACT>(v[u][k] * A[k] + Be[k], slope);
         d[u][k] = gzv * A[k] + (v[u][k] * B[k] + D[k]);
       }
       if (ru < rend) {
