@@ -13,11 +13,13 @@ pytestmark = pytest.mark.gpu
 JS, NPZ = load_golden()
 
 # bf16 gates AGAINST THE bf16-FAITHFUL ORACLE (oracle/vfd_oracle/bf16.py: the float32 oracle with a rounding at every tensor the
-# HIP path stores).  Measured with tools/probe/bf16_parity.py (profiles/r03_bf16_parity.txt); against the plain float32 oracle
-# the same quantities sit at 1e-2 .. 5e-2 (bf16 forward noise flips ~1 % of the ReLU / L1 kinks in any bf16 implementation).
-BF16_LOSS_TOL = 5e-3
+# HIP path stores; tests/test_bf16_faithful.py holds the per-kernel evidence).  Measured with tools/probe/bf16_parity.py
+# (profiles/r03_bf16_parity.txt): losses 1e-3 .. 9e-3, outputs 3e-3 .. 8e-3 relative RMS; against the plain float32 oracle the
+# same quantities sit at 1e-2 .. 5e-2.  Whole-net gradients are NOT tightened by the faithful oracle (single-ulp differences are
+# amplified x10-20 per stage in both directions: test_bf16_faithful.py) and keep bounds of that size.
+BF16_LOSS_TOL = 1e-2
 BF16_OUT_TOL = 1e-2
-BF16_GRAD_TOL = 0.35        # provisional, see the note at BF16_GRAD_MEDIAN_TOL
+BF16_GRAD_TOL = 0.35
 BF16_GRAD_MEDIAN_TOL = 0.2
 
 
@@ -68,24 +70,26 @@ def test_anogan_step_small(dt, dev, tmp_path):
     model.netd.load_state_dict(od.state_dict())
     _p0(model.netg)
     F.invalidate_weight_cache()
+    from vfd_oracle import bf16 as OB
     g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
     f32 = dt == torch.float32
+    ng, nd = (og, od) if f32 else (OB.Faithful(og), OB.Faithful(od))      # bf16: the bf16-faithful oracle
     for it in range(2):
         z, real = seeded_normal((B, 100), 10 + it), seeded_tensor((B, 3, T, S, S), 20 + it)
-        ref, fake_ref = OA.step(og, od, g_opt, d_opt, real, z)
+        ref, fake_ref = OA.step(ng, nd, g_opt, d_opt, real if f32 else OB.rbf(real), z if f32 else OB.rbf(z))
         model.set_input((real, real, real[:, :1], torch.ones(B, T)))
         model.z = z.to(dev)
         model.optimize_params()
         got = model.errors()
         for k, v in ref.items():
             g = got["%s/%s/train" % (k[4], k)]
-            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else (2e-2 if it == 0 else 6e-2)) * max(abs(v), 1e-3), (it, k, g, v)
         # step 0 compares the same weights; later steps also carry Adam's sign-amplified rounding noise of the
         # previous update (every weight moves ~lr whatever its gradient's size), hence the RMS metric there
         if f32 and it == 0:
             assert relerr(model.gen_fake.to_torch(), fake_ref) < 5e-4, it
         else:
-            assert relrms(model.gen_fake.to_torch(), fake_ref) < (5e-3 if f32 else 4e-2), (it, relrms(model.gen_fake.to_torch(), fake_ref))
+            assert relrms(model.gen_fake.to_torch(), fake_ref) < (5e-3 if f32 else (BF16_OUT_TOL if it == 0 else 4e-2)), (it, relrms(model.gen_fake.to_torch(), fake_ref))
     # A bias that feeds straight into a training-mode BatchNorm has an exactly-zero true gradient (the batch mean
     # absorbs it); what each implementation computes there is rounding noise, which Adam turns into +-lr moves.
     # The reference's own values for those entries are noise, so they are not compared.
@@ -145,23 +149,28 @@ def test_mygan_step_small(dt, dev, tmp_path):
     model.netd.load_state_dict(od.state_dict())
     _p0(model.netg)
     F.invalidate_weight_cache()
+    from vfd_oracle import bf16 as OB
     opt_g, opt_d = OM.make_optimizers(og, od)
     f32 = dt == torch.float32
+    ng, nd = (og, od) if f32 else (OB.Faithful(og), OB.Faithful(od))      # bf16: the bf16-faithful oracle
     for it in range(2):
         inp = seeded_tensor((B, 3, T, S, S), 30 + it)
         gt = (seeded_tensor((B, 1, T, S, S), 40 + it, 0.0, 1.0) > 0.97).float()
         gf, pf = seeded_tensor((B, 3, T, S, S), 50 + it), seeded_tensor((B, 3, T, S, S), 60 + it)
-        ref, pred_ref = OM.step(og, od, opt_g, opt_d, inp, gt, gf, pf)
+        if f32:
+            ref, pred_ref = OM.step(ng, nd, opt_g, opt_d, inp, gt, gf, pf)
+        else:
+            ref, pred_ref = OM.step(ng, nd, opt_g, opt_d, OB.rbf(inp), gt, OB.rbf(gf), OB.rbf(pf))
         model.set_input((inp, inp, gt, torch.ones(B, T)), gt_flow=gf, pre_flow=pf)
         model.optimize_params()
         got = model.errors()
         for k, v in ref.items():
             g = got["%s/%s/train" % (k[4], k)]
-            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else 6e-2) * max(abs(v), 1e-3), (it, k, g, v)
+            assert abs(g - v) <= ((1e-4 if it == 0 else 2e-4) if f32 else (1.5e-2 if it == 0 else 6e-2)) * max(abs(v), 1e-3), (it, k, g, v)
         if f32 and it == 0:
             assert relerr(model.predict.to_torch(), pred_ref) < 5e-4, it
         else:
-            assert relrms(model.predict.to_torch(), pred_ref) < (5e-3 if f32 else 4e-2), (it, relrms(model.predict.to_torch(), pred_ref))
+            assert relrms(model.predict.to_torch(), pred_ref) < (5e-3 if f32 else (BF16_OUT_TOL if it == 0 else 4e-2)), (it, relrms(model.predict.to_torch(), pred_ref))
     # (2+1)D conv biases all feed a BatchNorm: zero true gradient, see test_anogan_step_small
     _compare_state(model.netg.state_dict(), og.state_dict(), f32, 2e-5, 2, skip=("_conv.bias",))
     _compare_state(model.netd.state_dict(), od.state_dict(), f32, 2e-5, 2, skip=("_conv.bias",))
@@ -244,9 +253,16 @@ def test_anogan_generalised_112(dev, tmp_path):
     _p0(og)
     sd_g, sd_d = {k: v.clone() for k, v in og.state_dict().items()}, {k: v.clone() for k, v in od.state_dict().items()}
     z, real = seeded_normal((B, 100), 73), seeded_tensor((B, 3, T, S, S), 74)
+    from vfd_oracle import bf16 as OB
     g_opt, d_opt = OA.make_optimizers(og, od, 2e-5)
-    ref, fake_ref = OA.step(og, od, g_opt, d_opt, real, z)
-    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 5e-2)):
+    ref32, fake32 = OA.step(og, od, g_opt, d_opt, real, z)
+    # bf16 as benchmarked: against the bf16-faithful oracle on the same starting weights (2e-2: two clips only — the BCE terms are
+    # means over 2 sigmoid outputs of a 100k-feature Linear; measured 9.4e-3; frames 1e-2, measured 3.0e-3)
+    og.load_state_dict(sd_g)
+    od.load_state_dict(sd_d)
+    ref16, fake16 = OA.step(OB.Faithful(og), OB.Faithful(od), *OA.make_optimizers(og, od, 2e-5), OB.rbf(real), OB.rbf(z))
+    for dt, tol in ((torch.float32, 1e-4), (torch.bfloat16, 2e-2)):
+        ref, fake_ref = (ref32, fake32) if dt == torch.float32 else (ref16, fake16)
         F.set_compute_dtype(dt)
         model = HA.AnoGAN(_args(tmp_path, "anogan", B, T, S), None)
         assert model.netg.seed_shape == (512, 2, 14, 14) and model.netd.fc[0].in_features == 256 * 2 * 14 * 14
@@ -264,7 +280,7 @@ def test_anogan_generalised_112(dev, tmp_path):
         if dt == torch.float32:
             assert relerr(model.gen_fake.to_torch(), fake_ref) < 5e-4
         else:
-            assert relrms(model.gen_fake.to_torch(), fake_ref) < 4e-2
+            assert relrms(model.gen_fake.to_torch(), fake_ref) < BF16_OUT_TOL, relrms(model.gen_fake.to_torch(), fake_ref)
         del model
         torch.cuda.empty_cache()
     F.set_compute_dtype(torch.bfloat16)

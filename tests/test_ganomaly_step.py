@@ -10,6 +10,12 @@ from util import relerr, relrms
 
 pytestmark = pytest.mark.gpu
 
+# bf16 whole-step gates AGAINST THE bf16-FAITHFUL ORACLE (oracle/vfd_oracle/bf16.py; tests/test_bf16_faithful.py holds the
+# per-kernel evidence and explains why whole-net gradients are not tightened by it).  Measured on the bench configuration
+# (tools/probe/bf16_parity.py, profiles/r03_bf16_parity.txt): losses <= 1.4e-3, generated frames 7.8e-3 relative RMS.
+BF16_LOSS_TOL = 5e-3
+BF16_OUT_TOL = 1.5e-2
+
 
 def _args(tmp, B, T, S):
     return types.SimpleNamespace(batchsize=B, nfr=T, isize=S, ich=3, lr=2e-4, beta1=0.5, w_adv=1, w_con=50, freq=10 ** 9,
@@ -43,23 +49,27 @@ def test_ganomaly_step_parity(dt, S, ngf, extra, dev, tmp_path):
     from vfd_oracle import ganomaly as OG
     B, T = 2, 4
     model, og, od, opt = _build(tmp_path, dev, dt, B, T, S, ngf, extra)
+    from vfd_oracle import bf16 as OB
     opt_g, opt_d = OG.make_optimizers(og, od, opt)
     f32 = dt == torch.float32
+    # bf16: against the bf16-faithful oracle (same modules and optimisers, a rounding at every tensor the HIP path stores)
+    ng, nd = (og, od) if f32 else (OB.Faithful(og), OB.Faithful(od))
     for it in range(3):
         batch = synthetic_batch(B, T, S, 3, seed=100 + it)
         x = OG.fold_frames(batch[0])
-        errs_ref, fake_ref = OG.step(og, od, opt_g, opt_d, x, opt)
+        errs_ref, fake_ref = OG.step(ng, nd, opt_g, opt_d, x if f32 else OB.rbf(x), opt)
         model.set_input(batch)
         model.optimize_params(check_collapse=False)
         errs = model.errors()
-        tol_l = 1e-4 if f32 else 5e-2
+        # step 0 compares the same weights; later steps also carry Adam's +-lr moves of noise-level gradients (below)
+        tol_l = 1e-4 if f32 else (BF16_LOSS_TOL if it == 0 else 3e-2)
         for k, v in errs_ref.items():
             got = errs["%s/%s/train" % (k[4], k)]
             assert abs(got - v) <= tol_l * max(abs(v), 1e-3), (it, k, got, v)
         if f32:
             assert relerr(model.fake.to_torch(), fake_ref) < 2e-4, it
-        else:  # bf16 storage: stated tolerance 3e-2 relative RMS, 0.2 max-norm
-            assert relrms(model.fake.to_torch(), fake_ref) < 3e-2 and relerr(model.fake.to_torch(), fake_ref) < 0.2, it
+        else:
+            assert relrms(model.fake.to_torch(), fake_ref) < (BF16_OUT_TOL if it == 0 else 3e-2), (it, relrms(model.fake.to_torch(), fake_ref))
         if it in (0, 2):
             sdg, sdd = model.netg.state_dict(), model.netd.state_dict()
             lr = opt.lr
@@ -213,22 +223,24 @@ def test_ganomaly_bench_config_bf16_ngf64_112(dev, tmp_path):
     blind to an error at x_hat = 0, agrees to 1e-6).  The kernels' own accuracy at these tile sizes is gated by
     test_ganomaly_bench_tiles_smooth_bf16 below."""
     from vfd_gan_amd.lib.data import synthetic_batch
+    from vfd_oracle import bf16 as OB
     from vfd_oracle import ganomaly as OG
     B, T, S, ngf = 1, 16, 112, 64
     model, og, od, opt = _build(tmp_path, dev, torch.bfloat16, B, T, S, ngf)
     opt_g, opt_d = OG.make_optimizers(og, od, opt)
     batch = synthetic_batch(B, T, S, 3, seed=321)
-    errs_ref, fake_ref = OG.step(og, od, opt_g, opt_d, OG.fold_frames(batch[0]), opt)
+    # round 3: against the bf16-FAITHFUL oracle (losses 5e-2 -> 5e-3, frames 3e-2 -> 1.5e-2)
+    errs_ref, fake_ref = OG.step(OB.Faithful(og), OB.Faithful(od), opt_g, opt_d, OB.rbf(OG.fold_frames(batch[0])), opt)
     model.set_input(batch)
     model.optimize_params(check_collapse=False)
     errs = model.errors()
     for k, v in errs_ref.items():
         got = errs["%s/%s/train" % (k[4], k)]
-        assert abs(got - v) <= 5e-2 * max(abs(v), 1e-3), (k, got, v)
-    assert relrms(model.fake.to_torch(), fake_ref) < 3e-2
+        assert abs(got - v) <= BF16_LOSS_TOL * max(abs(v), 1e-3), (k, got, v)
+    assert relrms(model.fake.to_torch(), fake_ref) < BF16_OUT_TOL, relrms(model.fake.to_torch(), fake_ref)
     ge = _grad_errors(model, og, od)
     netd_keys = {k for k, _ in model.netd.named_parameters()}
-    bad = {k: v for k, v in ge.items() if v[2] > 1e-7 and not v[0] < (6e-2 if k in netd_keys else 0.2)}
+    bad = {k: v for k, v in ge.items() if v[2] > 1e-7 and not v[0] < (6e-2 if k in netd_keys else 0.15)}
     assert not bad, bad
 
 

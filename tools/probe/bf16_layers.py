@@ -134,6 +134,32 @@ def mygan():
         cmp("conv_last + sigmoid", hg.conv_last(hx, act=2), OB.run_seq([og.conv_last, og.sigmoid], ox))
 
 
+def anogan():
+    from vfd_gan_amd.models import anogan as HA
+    from vfd_oracle import anogan as OA
+    T, S = 16, 112
+    od = fill_module(OA.NetD(T, S), 72).train()
+    hd = HA.NetD(T, S).to(dev).train()
+    hd.load_state_dict(od.state_dict())
+    F.invalidate_weight_cache()
+    x = seeded_tensor((2, 3, T, S, S), 74)
+    print("anogan NetD (real)")
+    seq_prefixes("layer1", hd.layer1, od.layer1, x)
+    with torch.no_grad():
+        z = OB.run_seq(od.layer1, OB.rbf(x))
+    seq_prefixes("layer2", hd.layer2, od.layer2, z)
+    # per-channel |mean| / sigma of every conv output that feeds a BatchNorm (where float32 statistic sums lose digits)
+    with torch.no_grad():
+        h = OB.rbf(x)
+        mods = list(od.layer1) + list(od.layer2)
+        for i, m in enumerate(mods):
+            h2 = m(h)
+            if isinstance(m, nn.Conv3d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm3d):
+                mu, sd = h2.mean((0, 2, 3, 4)), h2.std((0, 2, 3, 4))
+                print("  conv %d -> BatchNorm: max |mean|/sigma %.1f (median %.2f)" % (i, float((mu.abs() / sd).max()), float((mu.abs() / sd).median())))
+            h = h2
+
+
 if __name__ == "__main__":
-    for w in (sys.argv[1:] or ["mygan", "ganomaly"]):
-        {"mygan": mygan, "ganomaly": ganomaly}[w]()
+    for w in (sys.argv[1:] or ["mygan", "ganomaly", "anogan"]):
+        {"mygan": mygan, "ganomaly": ganomaly, "anogan": anogan}[w]()
