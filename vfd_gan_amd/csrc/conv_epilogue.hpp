@@ -91,7 +91,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
         for (int r = 0; r < 4; ++r)
           if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
       }
-      S s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+      // (a lane's 4 x NJ values are added up in float32 — 4 terms — and the partials go to double from the shuffles on)
+      float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
       // BatchNorm hand-over: xh = x * ka + kb, z = xh * kg + kt for this lane's 4 channels; the producer BatchNorm's input
       // x at this lane's (pixel, 4 channels) positions, all loads of the pass in flight before the first use
       float ka[4], kb[4], kg[4], kt[4];
@@ -130,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float t = (SCALED ? acc[i][j][r] * p.oscale : acc[i][j][r]) + b4[r];
-            if (H == 0 && want_stats && pvalid[j]) { s1[r] += (S)t; s2[r] += (S)t * (S)t; }
+            if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
             v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
           }
         }
@@ -161,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
       if ((H == 0 || BN) && want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          S a = s1[r], b = s2[r];
+          S a = (S)s1[r], b = (S)s2[r];
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
           if ((lane & 15) == 0) {

@@ -113,21 +113,20 @@ template <> struct Mma<bf16_t> {
     constexpr int NJS = FLEX ? NJ - 1 : NJ;      // sub-tiles that are always in use
 #pragma unroll
     for (int ks = 0; ks < KSUB; ++ks) {
-      // (FLEX: the last sub-tile's fragment is read unconditionally — stale LDS bytes when it is unused — so that the register
-      // allocation is the plain tile's; only its MFMAs are skipped)
-      bf16x8 a[NI], b[NJ];
+      bf16x8 a[NI], b[NJS];
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(wt + lds_off<KSUB>(wrow0 + i * 16 + r, ch + 4 * ks));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, ch + 4 * ks));
+      for (int j = 0; j < NJS; ++j) b[j] = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + j * 16 + r, ch + 4 * ks));
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJS; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       if constexpr (FLEX) {
         if (last) {
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pt + lds_off<KSUB>(prow0 + (NJ - 1) * 16 + r, ch + 4 * ks));
 #pragma unroll
-          for (int i = 0; i < NI; ++i) acc[i][NJ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[NJ - 1], acc[i][NJ - 1], 0, 0, 0);
+          for (int i = 0; i < NI; ++i) acc[i][NJ - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bl, acc[i][NJ - 1], 0, 0, 0);
         }
       }
     }
@@ -316,19 +315,26 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? (
     const int co = n0 + g * RPI + lrow;
     wrow_off[i] = (g < NW && co < p.Cout) ? (uint32_t)(((long long)co * p.Kw) / VEC) : NONE;
   }
-  // pixel rows of this thread: the pixel index inside the class (M < 2^31, checked on the host), -1 = no pixel.  Its
-  // coordinates are decoded when the thread's chunk enters a new tap (every Cin / BK steps: 3 multiply-shift divisions per
-  // row there) instead of being kept in 4 registers per row for the whole loop: the 16-wave tiles live at a 128-register cap
-  // (FLEX tiles do not even keep the index: row -> pixel is a handful of scalar / vector operations, redone per tap)
-  auto pix_m = [&](int i) -> int {
+  // pixel rows of this thread
+  int pn[NPT], pid[NPT], pih[NPT], piw[NPT];
+  bool pgroup[NPT];       // FLEX: this wave-instruction's rows belong to a sub-tile in use (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
     const int g = wave + NWAVES * i;
     const long long m = row_m(g * RPI + lrow);
-    return (g < NP && m >= 0 && m < Mcls) ? (int)m : -1;
-  };
-  int pm[FLEX ? 1 : NPT];
-  if constexpr (!FLEX) {
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) pm[i] = pix_m(i);
+    pgroup[i] = !FLEX || row_m(g * RPI) >= 0;
+    if (g < NP && m >= 0 && m < Mcls) {
+      uint32_t q = (uint32_t)m, qw, qh, qd;     // M < 2^31 (checked on the host): multiply-shift divisions
+      fdivmod(q, dw.fq, q, qw);
+      fdivmod(q, dh.fq, q, qh);
+      fdivmod(q, dd.fq, q, qd);
+      pn[i] = (int)q;
+      pid[i] = (int)qd * dd.a + dd.c0;
+      pih[i] = (int)qh * dh.a + dh.c0;
+      piw[i] = (int)qw * dw.a + dw.c0;
+    } else {
+      pn[i] = -1; pid[i] = 0; pih[i] = 0; piw[i] = 0;
+    }
   }
   // per-tap state (recomputed only when this thread's chunk moves to another tap)
   uint32_t wtap_off = 0;        // tap index * Cip inside a filter row, in granules
@@ -341,15 +347,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? (
     const int od = td * dd.cs, oh = th * dh.cs, ow = tw * dw.cs;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-      const int pmi = FLEX ? pix_m(i) : pm[FLEX ? 0 : i];
-      uint32_t q = (uint32_t)(pmi < 0 ? 0 : pmi), qw, qh, qd;
-      fdivmod(q, dw.fq, q, qw);
-      fdivmod(q, dh.fq, q, qh);
-      fdivmod(q, dd.fq, q, qd);
-      const int id = (int)qd * dd.a + dd.c0 + od, ih = (int)qh * dh.a + dh.c0 + oh, iw = (int)qw * dw.a + dw.c0 + ow;
-      const bool ok = kvalid && pmi >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
+      const int id = pid[i] + od, ih = pih[i] + oh, iw = piw[i] + ow;
+      const bool ok = kvalid && pn[i] >= 0 && (unsigned)id < (unsigned)p.Di && (unsigned)ih < (unsigned)p.Hi &&
                       (unsigned)iw < (unsigned)p.Wi;
-      ppix_off[i] = ok ? (uint32_t)(((((int)q * p.Di + id) * p.Hi + ih) * p.Wi + iw)) * (uint32_t)(p.Cip / VEC) : NONE;
+      ppix_off[i] = ok ? (uint32_t)((((pn[i] * p.Di + id) * p.Hi + ih) * p.Wi + iw)) * (uint32_t)(p.Cip / VEC) : NONE;
     }
   };
   enter_tap();
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (WAVES_C * WAVES_P == 4 ? (
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
       const int g = wave + NWAVES * i;
-      if (FLEX && row_m(g * RPI) < 0) continue;      // rows of a sub-tile this tile does not use (wave-uniform): nothing reads them
+      if (FLEX && !pgroup[i]) continue;      // rows of a sub-tile this tile does not use: nothing reads them
       const char* src = (ppix_off[i] != NONE) ? reinterpret_cast<const char*>(xg) + ((size_t)ppix_off[i] << 4) + kc * (int)sizeof(T) : zero;
       const uint32_t dst = (NP % NWAVES == 0 || g < NP) ? pt + g * 1024 : smem_base + DUMP_OFF;
       dma16_to_lds(src, dst);
@@ -604,16 +605,7 @@ int launch(const ConvP& p, long long maxM, int ncls, hipStream_t st, size_t ws_b
     // Cout >= 256; 128c x 256p (8 waves) 540-740 for Cout = 128; the 4-wave 128 x 128 tile 520-690.
     if (variant == 1) return launch_cfg<T, 2, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 128c x 128p, 4 waves
     if (variant == 2) return launch_cfg<T, 2, 2, 4, 4, 2, 2>(p, maxM, ncls, st, ws_bytes, ws_query);   // ... 128-byte rows
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      // 128c x 512p, 16 waves (2 x 8), 128-byte rows, 2 stages, ALL 160 KiB of LDS, one workgroup per CU (round 3): the
-      // 8-wave 128c x 256p tile stages 24 KB per 512 MFMA cycles = 47 B/clk/CU over 64-byte rows, which the global->LDS path
-      // serves at 28 B/clk/CU: DMA-bound at ~60 %.  This shape needs 80 KB per 2048 cycles = 39 B/clk/CU of
-      // the 54 that 128-byte rows deliver.  FLEX: 24..32 sub-tiles of 16 pixels.
-      static const int big128 = getenv("VFD_IGEMM_128C_512P") ? atoi(getenv("VFD_IGEMM_128C_512P")) : 0;
-      if ((variant == 6 || (variant == 0 && big128)) && p.Cout <= 128 && p.mul.bn_mean == nullptr && maxM * ncls >= 64 * 512)
-        return launch_cfg<T, 2, 8, 4, 4, 2, 2, false, false>(p, maxM, ncls, st, ws_bytes, ws_query);
-    }
-    if (variant == 5 || ((variant == 0 || variant == 17 || variant == 6) && p.Cout <= 128))
+    if (variant == 5 || ((variant == 0 || variant == 17) && p.Cout <= 128))
       return launch_cfg<T, 2, 4, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);                   // 128c x 256p, 8 waves
     if (variant == 4 || variant == 17) return launch_cfg<T, 4, 2, 4, 4, 3, 1>(p, maxM, ncls, st, ws_bytes, ws_query);   // 256c x 128p, 8 waves
     // 256c x 256p, 16 waves (one workgroup per CU), 128-byte rows, 2 stages: the only tile whose DMA bytes per MFMA

@@ -199,12 +199,13 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
       for (int i = 0; i < NI_; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double a1 = 0.0, a2 = 0.0;
+          float f1 = 0.f, f2 = 0.f;      // a lane's CIN8_NJ values in float32, the partials in double from here on
 #pragma unroll
           for (int j = 0; j < CIN8_NJ; ++j) {
-            const double t = pxok_t[j] ? (double)v[(i * CIN8_NJ + j) * 4 + r] : 0.0;
-            a1 += t; a2 += t * t;
+            const float t = pxok_t[j] ? v[(i * CIN8_NJ + j) * 4 + r] : 0.f;
+            f1 += t; f2 += t * t;
           }
+          double a1 = (double)f1, a2 = (double)f2;
 #pragma unroll
           for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
           if ((lane & 15) == 0) {
