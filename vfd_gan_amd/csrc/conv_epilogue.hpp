@@ -50,7 +50,11 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
   typedef typename std::conditional<BN, float, double>::type S;      // accumulation type of the per-channel sums (BN hand-over: float)
-  constexpr int RED_BYTES = 2 * TILE_C * WAVES_P * (int)sizeof(S);
+  // statistics: the WAVES_P pixel-waves of a channel add their partials into ONE double per channel with LDS atomics
+  // ([2][TILE_C] doubles: with a slot per wave the doubles pushed the 128-channel tile's epilogue into two passes, +3.5 % on
+  // its launches); the BN hand-over keeps its float slot per wave (its two passes accumulate into their own slots)
+  constexpr bool ATOM = !BN;
+  constexpr int RED_BYTES = ATOM ? 2 * TILE_C * (int)sizeof(S) : 2 * TILE_C * WAVES_P * (int)sizeof(S);
     // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
   constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
                      : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
@@ -77,6 +81,12 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     for (int r = tid; r < TILE_P; r += 64 * NWAVES) orow[r] = out_offset(r);
     if constexpr (BN) __syncthreads();      // the accumulator pass below already needs the row offsets
   }
+  if constexpr (ATOM) {
+    if (want_stats) {
+      for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) red[t] = 0;
+      __syncthreads();      // zeroed before the first wave adds
+    }
+  }
   // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
   // accumulator tile across a store phase); the statistics of all sub-tiles are taken in pass 0
   auto body = [&](auto actf, auto hc) {
@@ -91,7 +101,9 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
         for (int r = 0; r < 4; ++r)
           if ((c + r) < p.Cout) b4[r] = p.bias[c + r];
       }
-      // (a lane's 4 x NJ values are added up in float32 — 4 terms — and the partials go to double from the shuffles on)
+      // (a wave's 16 lanes x NJ pixels are added up in float32 — 64 terms, as in rounds 1-2: double shuffles cost 5 % of the
+      // 128-channel tile's launch — and the per-wave partials go to double: LDS fold, atomics, the BatchNorm fold.  Relative
+      // error of the variance ~ 2.4e-7 (|mean|/sigma)^2 / sqrt(number of wave partials): 3e-6 at a ratio of 30 over 400k pixels)
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
       // BatchNorm hand-over: xh = x * ka + kb, z = xh * kg + kt for this lane's 4 channels; the producer BatchNorm's input
       // x at this lane's (pixel, 4 channels) positions, all loads of the pass in flight before the first use
@@ -162,17 +174,23 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
       if ((H == 0 || BN) && want_stats) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          S a = (S)s1[r], b = (S)s2[r];
+          float af = s1[r], bf = s2[r];
 #pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+          for (int o = 1; o < 16; o <<= 1) { af += __shfl_xor(af, o, 64); bf += __shfl_xor(bf, o, 64); }
+          S a = (S)af, b = (S)bf;
           if ((lane & 15) == 0) {
             const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
-            if (BN && H != 0) {        // the hand-over sums are taken as the sub-tiles are emitted: pass 1 adds to pass 0 (same lane)
-              a += red[cl * WAVES_P + (wave / WAVES_C)];
-              b += red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)];
+            if constexpr (ATOM) {
+              atomicAdd(red + cl, a);                      // ds_add_f64
+              atomicAdd(red + TILE_C + cl, b);
+            } else {
+              if (H != 0) {        // the hand-over sums are taken as the sub-tiles are emitted: pass 1 adds to pass 0 (same lane)
+                a += red[cl * WAVES_P + (wave / WAVES_C)];
+                b += red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)];
+              }
+              red[cl * WAVES_P + (wave / WAVES_C)] = a;
+              red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
             }
-            red[cl * WAVES_P + (wave / WAVES_C)] = a;
-            red[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = b;
           }
         }
       }
@@ -252,8 +270,12 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
       const int which = t / TILE_C, cl = t - which * TILE_C;
       S v = 0;
+      if constexpr (ATOM) {
+        v = red[t];
+      } else {
 #pragma unroll
-      for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
+        for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
+      }
       if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);      // global_atomic_add_f32 / _f64: one per channel and workgroup
     }
   }

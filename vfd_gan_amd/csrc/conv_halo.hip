@@ -63,7 +63,7 @@ struct HaloCfg {
   static constexpr int HALO_BYTES = (ROWS_MAX + 15) / 16 * 1024;
   static constexpr int FTAP = TILE_C * 64;                    // one tap's filter slice
   static constexpr int FSTAGE = 3 * FTAP;                     // the (up to 3) w-taps of one (kd, kh)
-  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 8 + 256 * 8;      // output rows + [2][TILE_C][4 waves] double sums + row offsets
+  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 4 + 256 * 8;      // output rows + per-channel sums ([2][TILE_C] doubles, or the hand-over's [2][TILE_C][4] floats) + row offsets
   static constexpr int NFS = 2;                               // filter ring depth
   static constexpr int LDS = (HALO_BYTES + NFS * FSTAGE > EPI_BYTES) ? HALO_BYTES + NFS * FSTAGE : EPI_BYTES;
   static constexpr int NHW = ((ROWS_MAX + 15) / 16 + 3) / 4;  // halo DMA instructions per wave (upper bound)
