@@ -38,6 +38,12 @@ CONV_CASES = [
     # <= 64 channels on the strided side with >= 256 filter columns: the 64 x 256 filter-gradient tile (128-byte rows)
     ("K1_conv3d_k3_64to64", (1, 64, 3, 9, 9), 64, 3, 1, 1, 0, False, True),
     ("K1_conv3d_k3_40to50", (2, 40, 2, 6, 7), 50, 3, 1, 1, 0, False, False),
+    # >= 256 (filter row, 64-gather-channel chunk) pairs: the LDS-turned slab fold (wgrad_reduce_turn_kernel) — whole and partial
+    # (60 of 64) channel chunks, 16 / 9 / 49 taps, regular and transposed, with and without the bias rows
+    ("K6_conv2d_k4s2_64to256_turn", (2, 64, 8, 8), 256, 4, 2, 1, 0, False, True),
+    ("K6_conv2d_k3_60to256_turn", (2, 60, 6, 6), 256, 3, 1, 1, 0, False, False),
+    ("K6_conv2d_k7_128to130_turn", (3, 128, 7, 7), 130, 7, 1, 0, 0, False, True),
+    ("K6_convT2d_k4s2_256to64_turn", (2, 256, 4, 4), 64, 4, 2, 1, 0, True, True),
     # 517 tiles of 128c x 256p on 512 workgroup slots (more than one round of workgroups, XCD-ordered ids)
     ("K6_conv2d_k1_517tiles", (3, 8, 210, 210), 128, 1, 1, 0, 0, False, True),
     # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients
