@@ -8,6 +8,8 @@ re-packing — is captured ONCE into a hipGraph (torch.cuda.CUDAGraph supplies t
 memory pool) and replayed per step.  Host-side decisions of the reference step stay outside the graph: loading the
 next batch into the static input buffer, and ganomaly's ``err_d.item() < 1e-5 -> reinit_d()`` check.
 """
+import gc
+
 import torch
 
 from . import functional as F
@@ -67,6 +69,13 @@ class GraphedStep:
             r.suspended = True         # no collective may be issued while a capture is open
         self.program = []
         pool = None
+        # Cyclic garbage must not be collected while a capture is open: a collected CUDAGraph / private-pool block of an earlier
+        # GraphedStep frees device memory from its destructor, which is not permitted on a capturing thread and aborts the
+        # process (round 3, tests/test_ganomaly_step.py after other graph tests; torch >= 2.9 no longer collects on entry to
+        # torch.cuda.graph unless torch.compiler.config.force_cudagraph_gc is set).  Collect now, hold the collector until done.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             for kind, obj in program:
                 if kind == "graph":
@@ -87,6 +96,8 @@ class GraphedStep:
                 else:
                     self.program.append((kind, obj, None))
         finally:
+            if gc_was_on:
+                gc.enable()
             for r in reducers:
                 r.suspended = False
                 r.reset()
