@@ -29,10 +29,17 @@ CASES = [
     ("c2d_k3_64to64", (3, 64, 20, 24), 64, 3, 1, 1, 0, False, True),             # frames: 1 x 16 x 16 tile
     ("c2d_k3_48to20", (2, 48, 17, 30), 20, 3, 1, 1, 0, False, False),
     ("t3d_k3s1_128to64", (1, 128, 4, 8, 16), 64, 3, 1, 1, 0, True, True),        # anogan NetG layer3[1]
-    ("t2d_k4s2_128to64", (2, 128, 14, 14), 64, 4, 2, 1, 0, True, False),         # ganomaly decoder pyramid (4 classes, 2x2 taps)
+    ("t2d_k4s2_128to64_rows14", (2, 128, 14, 14), 64, 4, 2, 1, 0, True, False),   # ganomaly decoder pyramid (4 classes, 2x2 taps)
     ("t2d_k4s2_40to24", (2, 40, 13, 15), 24, 4, 2, 1, 0, True, True),
     ("t3d_k3s2_64to32", (1, 64, 3, 7, 12), 32, 3, 2, 1, 1, True, True),          # classes with 1 and 2 taps per dim
+    # frames under 2 x 2-tap classes (k4 s2 p1 transposed): conv_halo_rows (16 virtual rows x 16 pixels, one shared zero row
+    # between frames, 4 workgroups per CU).  ganomaly's decoder / data-gradient shape; a partial channel chunk with partial
+    # output channels, a 14-row period and partial width tiles; 5 frames of 13 rows (tiles span frames, 70 virtual rows)
+    ("t2d_k4s2_128to64_rows", (3, 128, 28, 28), 64, 4, 2, 1, 0, True, False),
+    ("t2d_k4s2_40to50_rows56", (2, 40, 13, 56), 50, 4, 2, 1, 0, True, True),
+    ("t2d_k4s2_64to64_rows_frames", (5, 64, 13, 28), 64, 4, 2, 1, 0, True, True),
 ]
+ROWS = {c[0] for c in CASES if "_rows" in c[0]}
 
 
 def _run(case, halo_mode, dev, act=0, slope=0.0, stats=False, wg_mode=1):
@@ -75,7 +82,7 @@ def test_halo_forward_and_gradients(case, dev):
     name, xs, cout, k, s, p, op, tr, has_bias = case
     nd = len(xs) - 2
     h = _run(case, 2, dev)
-    assert h["name"].startswith("conv_halo<bf16"), h["name"]        # the layer really went to the halo kernel
+    assert h["name"].startswith("conv_halo_rows<bf16" if name in ROWS else "conv_halo<bf16"), h["name"]        # the layer really went to the halo kernel
     g = _run(case, 1, dev)
     xr, wr = h["x"].clone().requires_grad_(), h["w"].clone().requires_grad_()
     br = h["b"].clone().requires_grad_() if has_bias else None
@@ -105,6 +112,21 @@ def test_halo_fused_activation_and_statistics(act, slope, dev):
     from vfd_gan_amd import functional as F
     folded = h["sums"].view(F.STATS_REPLICAS, 2, 64).sum(0)
     assert relerr(folded[0], pre.sum(dim=(0, 2, 3, 4))) < 1e-4 and relerr(folded[1], (pre * pre).sum(dim=(0, 2, 3, 4))) < 1e-4
+
+
+@pytest.mark.parametrize("act,slope", [(1, 0.2), (3, 0.0)], ids=["lrelu", "tanh"])
+def test_halo_rows_fused_activation_and_statistics(act, slope, dev):
+    """The same epilogue fusions through conv_halo_rows (7-wave tile; the zero rows between frames and the rows past the last
+    frame must stay out of the statistics)."""
+    case = ("t2d_k4s2_64to64_rows_act", (3, 64, 13, 28), 64, 4, 2, 1, 0, True, True)
+    h = _run(case, 2, dev, act, slope, stats=True)
+    assert h["name"].startswith("conv_halo_rows<bf16"), h["name"]
+    pre = TF.conv_transpose2d(h["x"], h["w"], h["b"], 2, 1)
+    ref = {1: TF.leaky_relu(pre, slope), 3: torch.tanh(pre)}[act]
+    assert relerr(h["y"], ref) < TOL[torch.bfloat16]
+    from vfd_gan_amd import functional as F
+    folded = h["sums"].view(F.STATS_REPLICAS, 2, 64).sum(0)
+    assert relerr(folded[0], pre.sum(dim=(0, 2, 3))) < 1e-4 and relerr(folded[1], (pre * pre).sum(dim=(0, 2, 3))) < 1e-4
 
 
 def test_halo_activation_gradient_handover(dev):

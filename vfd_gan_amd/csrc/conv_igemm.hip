@@ -751,7 +751,12 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
     snprintf(buf, n, "%s<%s>", (cpad(dn.Cin) == 8 || pointwise) ? "conv_cin8" : "convt_thin", t);
     return VFD_OK;
   }
-  if (vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, no_mul(), true, nullptr) > 0) {
+  const int halo = vfd_conv_halo_try(&dn, nullptr, nullptr, nullptr, nullptr, nullptr, no_mul(), true, nullptr);
+  if (halo == 2) {
+    snprintf(buf, n, "conv_halo_rows<%s,64c_x_256p>", t);
+    return VFD_OK;
+  }
+  if (halo > 0) {
     snprintf(buf, n, "conv_halo<%s,%s>", t, dn.Cout > 32 ? "64c_x_256p" : "32c_x_256p");
     return VFD_OK;
   }
