@@ -314,6 +314,15 @@ int vfd_maxpool_backward(int dtype, const void* dy, const void* idx, void* dx, i
 /* y = a + b (+ c when non-null), n elements (a multiple of 8), summed in float32 and rounded once: the residual join
  * `x += skip` of models/xception.py:68, and the sum of the gradients returning to a tensor with several consumers. */
 int vfd_add(int dtype, const void* a, const void* b, const void* c, void* y, int64_t n, void* stream);
+/* Zero fill of `bytes` bytes at a 16-byte-aligned address (statistics / sum pools, the gradient arenas of
+ * optimizer.zero_grad(), models/ganomaly.py:514,517): capture-safe like everything else here. */
+int vfd_zero(void* p, size_t bytes, void* stream);
+/* The scalar arithmetic of a step's loss terms on the device, n = 1..4 float32 scalars:
+ *   *out = sum_i w_i * *t_i   (models/ganomaly.py:487-490 err_g, :511 err_d; models/mygannet.py:416-433), left to right in float32;
+ * vfd_scale4 is its backward: out[i] = *g * w_i. */
+int vfd_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1, float w2,
+                      float w3, int n, float* out, void* stream);
+int vfd_scale4(const float* g, float w0, float w1, float w2, float w3, int n, float* out, void* stream);
 /* torch.cat([Upsample(x), skip], dim=1) in one pass (U-Net decoder joint, models/mygannet.py:78-94): x [N][D][H][W][Ca]
  * (Ca a multiple of 8), skip [N][2D][2H][2W][CPAD(Cb)], y [N][2D][2H][2W][Ca + CPAD(Cb)]; the up-sampled tensor is never
  * materialised.  Backward: dx from the first Ca channels of dcat read in place, dskip = the remaining channels.     */

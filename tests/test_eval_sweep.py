@@ -31,6 +31,11 @@ def test_morph_open5x5_matches_restatement(dev):
         got = morphology_proc(threshold(x.to(dev))).cpu().numpy()
         assert 0 < ref.sum() < ref.size
         assert np.array_equal(got, ref), shape
+        # literal=True: the plane the reference's loop hands to cv2 — (T,H) per W column (lib/utils.py:143: cv2 reads a (T,H,W)
+        # array as rows, cols, channels); same restatement applied to the permuted block
+        ref_l = np.transpose(morph_open5(np.transpose(t.numpy(), (0, 1, 4, 2, 3))), (0, 1, 3, 4, 2))
+        got_l = morphology_proc(threshold(x.to(dev)), literal=True).cpu().numpy()
+        assert np.array_equal(got_l, ref_l), shape
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

@@ -89,6 +89,9 @@ SIGNATURES = {
     "vfd_maxpool_forward": (c_int, [c_int, c_vp, c_vp, c_vp] + [c_int] * 14 + [c_vp]),
     "vfd_maxpool_backward": (c_int, [c_int, c_vp, c_vp, c_vp] + [c_int] * 14 + [c_vp]),
     "vfd_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vfd_zero": (c_int, [c_vp, ctypes.c_size_t, c_vp]),
+    "vfd_weighted_sum4": (c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_int, c_vp, c_vp]),
+    "vfd_scale4": (c_int, [c_vp, c_f32, c_f32, c_f32, c_f32, c_int, c_vp, c_vp]),
     "vfd_upsample2x_cat_forward": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_upsample2x_cat_backward": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vfd_morph_open5x5": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_f32, c_int, c_vp]),

@@ -189,6 +189,34 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, con
   }
 }
 
+// ---- zero fill (statistics / sum pools, gradient arenas) and the scalar arithmetic of a step's loss terms: the last
+// torch element-wise operators on the hot path (round 2's profiles: 24 at::native launches per ganomaly step)
+__global__ void zero_kernel(uint4* __restrict__ p, long long n16, char* __restrict__ tail, int ntail) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+// out = sum_i w[i] * *t[i]  (err_g = w_adv * err_g_adv + w_con * err_g_con + w_enc * err_g_enc, models/ganomaly.py:487-490;
+// err_d = (err_d_real + err_d_fake) * 0.5, :511); summed left to right in float32 like the torch expression
+__global__ void weighted_sum4_kernel(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1, float w2,
+                                     float w3, int n, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = *t0 * w0;
+  if (n > 1) s += *t1 * w1;
+  if (n > 2) s += *t2 * w2;
+  if (n > 3) s += *t3 * w3;
+  *out = s;
+}
+// ... and its backward: out[i] = *g * w[i]
+__global__ void scale4_kernel(const float* __restrict__ g, float w0, float w1, float w2, float w3, int n, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float v = *g;
+  out[0] = v * w0;
+  if (n > 1) out[1] = v * w1;
+  if (n > 2) out[2] = v * w2;
+  if (n > 3) out[3] = v * w3;
+}
+
 // ---- activation ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long long rows, int C, int act, float slope) {
@@ -508,6 +536,33 @@ extern "C" int vfd_add(int dtype, const void* a, const void* b, const void* c, v
   else
     hipLaunchKernelGGL(add_kernel<float>, dim3(ew_blocks(n8)), dim3(EW_THREADS), 0, as_stream(stream), (const float*)a, (const float*)b, (const float*)c, (float*)y, n8);
   VFD_CHECK_LAUNCH("add");
+  return VFD_OK;
+}
+
+extern "C" int vfd_zero(void* p, size_t bytes, void* stream) {
+  VFD_REQUIRE(p != nullptr || bytes == 0, "zero: null pointer");
+  if (bytes == 0) return VFD_OK;
+  VFD_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, "zero: the buffer must be 16-byte aligned");
+  const long long n16 = (long long)(bytes >> 4);
+  const int ntail = (int)(bytes & 15);
+  hipLaunchKernelGGL(zero_kernel, dim3(ew_blocks(n16 > 0 ? n16 : 1)), dim3(EW_THREADS), 0, as_stream(stream), reinterpret_cast<uint4*>(p), n16,
+                     reinterpret_cast<char*>(p) + (n16 << 4), ntail);
+  VFD_CHECK_LAUNCH("zero");
+  return VFD_OK;
+}
+
+extern "C" int vfd_weighted_sum4(const float* t0, const float* t1, const float* t2, const float* t3, float w0, float w1, float w2,
+                                 float w3, int n, float* out, void* stream) {
+  VFD_REQUIRE(n >= 1 && n <= 4 && t0 && out && (n < 2 || t1) && (n < 3 || t2) && (n < 4 || t3), "weighted_sum4: bad arguments");
+  hipLaunchKernelGGL(weighted_sum4_kernel, dim3(1), dim3(64), 0, as_stream(stream), t0, t1, t2, t3, w0, w1, w2, w3, n, out);
+  VFD_CHECK_LAUNCH("weighted_sum4");
+  return VFD_OK;
+}
+
+extern "C" int vfd_scale4(const float* g, float w0, float w1, float w2, float w3, int n, float* out, void* stream) {
+  VFD_REQUIRE(n >= 1 && n <= 4 && g && out, "scale4: bad arguments");
+  hipLaunchKernelGGL(scale4_kernel, dim3(1), dim3(64), 0, as_stream(stream), g, w0, w1, w2, w3, n, out);
+  VFD_CHECK_LAUNCH("scale4");
   return VFD_OK;
 }
 

@@ -120,6 +120,56 @@ def join_side_stream():
         _SIDE["dirty"] = False
 
 
+def zero_(t):
+    """t[:] = 0 through the library's own fill (vfd_zero): no torch element-wise operator on the hot path."""
+    if t.numel():
+        if not t.is_contiguous():
+            raise RuntimeError("zero_: contiguous tensors only")
+        check(load().vfd_zero(t.data_ptr(), t.numel() * t.element_size(), stream()), "zero")
+    return t
+
+
+def zeros(shape, dtype, device):
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
+class _WeightedSum(torch.autograd.Function):
+    """sum_i w_i * t_i of up to four float32 device scalars in ONE launch (backward: one launch for all terms): the
+    `err_g = err_g_adv * w_adv + err_g_con * w_con + ...` lines of the reference steps (models/ganomaly.py:487-490,
+    models/mygannet.py:416-433), which as torch expressions cost a multiply / add launch per operator in both directions."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        n = len(terms)
+        ts = [t.detach().float().contiguous() for t in terms]
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        w = list(weights) + [0.0] * (4 - n)
+        p = [t.data_ptr() for t in ts] + [None] * (4 - n)
+        check(load().vfd_weighted_sum4(p[0], p[1], p[2], p[3], w[0], w[1], w[2], w[3], n, out.data_ptr(), stream()), "weighted_sum4")
+        ctx.weights = w
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, w = ctx.n, ctx.weights
+        g = g.contiguous().float()
+        out = torch.empty(4, dtype=torch.float32, device=g.device)
+        check(load().vfd_scale4(g.data_ptr(), w[0], w[1], w[2], w[3], n, out.data_ptr(), stream()), "scale4")
+        return (None,) + tuple(out[i] if ctx.needs_input_grad[1 + i] else None for i in range(n))
+
+
+def weighted_sum(*pairs):
+    """weighted_sum((t0, w0), (t1, w1), ...) -> float32 scalar tensor sum_i w_i * t_i (1..4 terms, summed left to right)."""
+    if not 1 <= len(pairs) <= 4:
+        raise ValueError("weighted_sum takes 1..4 (tensor, weight) pairs")
+    terms = [t for t, _ in pairs]
+    for t in terms:
+        if t.numel() != 1 or t.dtype != torch.float32 or not t.is_cuda:
+            raise RuntimeError("weighted_sum: float32 device scalars only")
+    return _WeightedSum.apply(tuple(float(w) for _, w in pairs), *terms)
+
+
 def stats_buffer_numel(C):
     """Elements of a [STATS_REPLICAS][2][CPAD(C)] sums buffer: float64 for a conv epilogue's forward statistics
     (new_stats_buffer), float32 for the BatchNorm backward sums / bias-gradient rows."""
@@ -129,7 +179,7 @@ def stats_buffer_numel(C):
 def new_stats_buffer(channels, device):
     """Zeroed [STATS_REPLICAS][2][CPAD(C)] FLOAT64 buffer for a conv epilogue's BatchNorm partial sums (the kernels add up
     their float32 accumulators in double: include/vfdgan_hip.h, vfd_conv_forward)."""
-    return torch.zeros(STATS_REPLICAS * 2 * cpad(channels), dtype=torch.float64, device=device)
+    return zeros(STATS_REPLICAS * 2 * cpad(channels), torch.float64, device)
 
 
 def _stats_arg(stats):
@@ -941,7 +991,7 @@ class _BnActPool(torch.autograd.Function):
         N, D, H, W, C, act, slope, (pd, ph, pw) = ctx.meta
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if gp is None:          # only the full-resolution output was used
-            gp = torch.zeros((N, D // pd, H // ph, W // pw, x.shape[-1]), dtype=x.dtype, device=x.device)
+            gp = zeros((N, D // pd, H // ph, W // pw, x.shape[-1]), x.dtype, x.device)
         gp = gp.contiguous()
         gfull = gfull.contiguous() if gfull is not None else None
         dev = x.device

@@ -70,20 +70,34 @@ def threshold(data):
     return (t > 0.5).float()
 
 
-def morphology_proc(video):
-    """Reference lib/utils.py:139-147: 5 x 5 morphological opening of every frame of a (N,1,T,H,W) mask — there on the CPU
-    through cv2 with a device -> host -> device round trip, here one HIP launch pair on the device (vfd_morph_open5x5;
-    cv2's default border: pixels outside the frame do not take part).  Returns a float32 device tensor of the input's shape."""
+def morphology_proc(video, literal=False):
+    """Reference lib/utils.py:139-147: 5 x 5 morphological opening of a (N,1,T,H,W) mask — there on the CPU through cv2 with a
+    device -> host -> device round trip, here one HIP launch pair on the device (vfd_morph_open5x5; cv2's default border:
+    pixels outside the plane do not take part).  Returns a float32 device tensor of the input's shape.
+
+    WHICH plane is opened is a deliberate deviation ("parity unpinned"): the reference's loop
+    ``for v in video: [cv2.morphologyEx(i, ...) for i in v]`` hands cv2 the whole (T,H,W) block of a clip, which cv2 reads as
+    rows = T, cols = H, channels = W — the code as executed opens the (T,H) plane of every W column.  The default here opens
+    every (H,W) FRAME, what the function's name, its caller (a per-frame foreground mask, models/mygannet.py:404-407) and
+    the kernel size say was meant.  ``literal=True`` reproduces the executed behaviour (planes = N*W over the (T,H) axes).
+    Either way cv2 is absent from this image: the opening is pinned by scipy.ndimage.grey_opening, not by cv2 output, and the
+    scores test() derives from it are not claimed to match the reference's."""
     from .._lib import check, load, require_device, stream
     t = video.to_torch() if isinstance(video, ClTensor) else video
     require_device(t)
     t = t.contiguous().float()
     if t.dim() < 3:
         raise RuntimeError("morphology_proc expects (..., H, W) frames")
+    if literal:
+        if t.dim() != 5:
+            raise RuntimeError("morphology_proc(literal=True) expects the reference's (N,1,T,H,W) block")
+        t = t.permute(0, 1, 4, 2, 3).contiguous()         # (N,1,W,T,H): planes of (T,H)
     H, W = int(t.shape[-2]), int(t.shape[-1])
     planes = t.numel() // (H * W)
     tmp, out = torch.empty_like(t), torch.empty_like(t)
     check(load().vfd_morph_open5x5(t.data_ptr(), tmp.data_ptr(), out.data_ptr(), planes, H, W, 0.0, 0, stream()), "morph_open5x5")
+    if literal:
+        out = out.permute(0, 1, 3, 4, 2).contiguous()
     return out
 
 

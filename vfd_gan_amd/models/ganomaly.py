@@ -260,9 +260,8 @@ class Ganomaly(GANBaseModel):
             self.err_g_adv = self.l_adv(self.feat_real.detach(), self.feat_fake)
             self.err_g_con = self.l_con(self.fake, self.x)
             self.err_g_enc = self.l_enc(self.latent_o, self.latent_i)
-            self.err_g = self.err_g_adv * self.opt.w_adv + \
-                         self.err_g_con * self.opt.w_con + \
-                         self.err_g_enc * self.opt.w_enc
+            self.err_g = F.weighted_sum((self.err_g_adv, self.opt.w_adv), (self.err_g_con, self.opt.w_con),
+                                        (self.err_g_enc, self.opt.w_enc))
             # netd(fake)'s graph is walked again by backward_d: keep it
             torch.autograd.backward(self.err_g, inputs=[p for p in self.netg.parameters() if p.requires_grad], retain_graph=True)
         finally:
@@ -275,9 +274,9 @@ class Ganomaly(GANBaseModel):
     def backward_d(self, join=True):
         self.err_d_real = self.l_bce(self.pred_real, self.real_label)
         self.err_d_fake = self.l_bce(self.pred_fake, self.fake_label)
-        self.err_d = (self.err_d_real + self.err_d_fake) * 0.5
+        self.err_d = F.weighted_sum((self.err_d_real, 0.5), (self.err_d_fake, 0.5))
         for pool in self._dfake_pools:          # BatchNorm / bias sum buffers of netd(fake): second walk of that graph
-            pool.zero_()
+            F.zero_(pool)
         skip = self.fake_d.t.data_ptr()         # ... which stops at netD's first layer (the reference detaches fake here)
         F._SKIP_INPUT_GRAD.add(skip)
         try:

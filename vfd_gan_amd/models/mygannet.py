@@ -31,7 +31,7 @@ def _conv_bn_act(block, x, slope, pool=None, keep_full=False):
     (pooled, full) is returned): absorbed into the BatchNorm pass where it can be (functional._BnActPool)."""
     if block.bn.training and hnn.use_epilogue_stats(x):
         k = F.stats_buffer_numel(block.bn.num_features)
-        buf = torch.zeros(4 * k, dtype=torch.float32, device=x.t.device)      # forward statistics (float64) | backward sums | bias sums: one fill
+        buf = F.zeros(4 * k, torch.float32, x.t.device)      # forward statistics (float64) | backward sums | bias sums: one fill
         fstats, bsums, brep = buf[:2 * k].view(torch.float64), buf[2 * k:3 * k], buf[3 * k:]
         tbias = block.conv.temporal_conv.bias
         tok = {"taken": False, "rep": brep} if tbias is not None else None
@@ -243,9 +243,9 @@ class MyGAN(GANBaseModel):
         # evaluated for its VALUE only, and only the reconstruction term is back-propagated.
         err_g_adv_s = self.l_adv(self.s_feat_real.detach(), self.s_feat_fake.detach())
         err_g_adv_t = self.l_adv(self.t_feat_real.detach(), self.t_feat_fake.detach())
-        err_g_adv = err_g_adv_s + err_g_adv_t
+        err_g_adv = F.weighted_sum((err_g_adv_s, 1.0), (err_g_adv_t, 1.0))
         err_g_con = self.l_con(self.predict, self.gt_cl)
-        err_g = err_g_adv * self.args.w_adv + err_g_con * self.args.w_con
+        err_g = F.weighted_sum((err_g_adv, self.args.w_adv), (err_g_con, self.args.w_con))
         err_g.backward()
         if join:
             self.reducer_g.finish()
@@ -257,9 +257,9 @@ class MyGAN(GANBaseModel):
         err_d_real_t = self.l_bce(self.t_pred_real, self.real_label)
         err_d_fake_s = self.l_bce(self.s_pred_fake, self.gout_label)
         err_d_fake_t = self.l_bce(self.t_pred_fake, self.gout_label)
-        err_d_real = (err_d_real_s + err_d_real_t) * 0.5
-        err_d_fake = (err_d_fake_s + err_d_fake_t) * 0.5
-        err_d = (err_d_real + err_d_fake) * 0.5
+        err_d_real = F.weighted_sum((err_d_real_s, 0.5), (err_d_real_t, 0.5))
+        err_d_fake = F.weighted_sum((err_d_fake_s, 0.5), (err_d_fake_t, 0.5))
+        err_d = F.weighted_sum((err_d_real, 0.5), (err_d_fake, 0.5))
         self.errors_dict.update({'d/err_d_real_s/train': err_d_real_s, 'd/err_d_real_t/train': err_d_real_t,
                                  'd/err_d_fake_s/train': err_d_fake_s, 'd/err_d_fake_t/train': err_d_fake_t,
                                  'd/err_d_real/train': err_d_real, 'd/err_d_fake/train': err_d_fake, 'd/err_d/train': err_d})
@@ -352,11 +352,11 @@ class MyGAN(GANBaseModel):
             e = {k: torch.stack([v.detach().float().reshape(()) for v in acc[k]]).cpu().numpy().astype(np.float64) for k in keys}
             gts_np = np.asarray(torch.stack(gts).cpu().numpy(), dtype=np.int32).flatten()
             pre_np = np.asarray(torch.stack(predicts).cpu().numpy()).flatten()
-        err_g_adv = e["err_g_adv_s"] + e["err_g_adv_t"]
-        err_g = e["err_g_adv_t"] * self.args.w_adv + e["err_g_con"] * self.args.w_con      # reference :416: temporal term only
-        err_d_real = (e["err_d_real_s"] + e["err_d_real_t"]) * 0.5
-        err_d_fake = (e["err_d_fake_s"] + e["err_d_fake_t"]) * 0.5
-        err_d = (err_d_real + err_d_fake) * 0.5
+        err_g_adv = F.weighted_sum((e["err_g_adv_s"], 1.0), (e["err_g_adv_t"], 1.0))
+        err_g = F.weighted_sum((e["err_g_adv_t"], self.args.w_adv), (e["err_g_con"], self.args.w_con))      # reference :416: temporal term only
+        err_d_real = F.weighted_sum((e["err_d_real_s"], 0.5), (e["err_d_real_t"], 0.5))
+        err_d_fake = F.weighted_sum((e["err_d_fake_s"], 0.5), (e["err_d_fake_t"], 0.5))
+        err_d = F.weighted_sum((err_d_real, 0.5), (err_d_fake, 0.5))
         saveto = self.save_root_dir if self.rank == 0 else None
         roc = evaluate(gts_np, pre_np, self.best_roc, self.epoch, saveto, metric='roc')
         pr = evaluate(gts_np, pre_np, self.best_pr, self.epoch, saveto, metric='pr')

@@ -251,7 +251,7 @@ def run_fused(mods, x, last_stats=None, last_bias_token=None):
             if handover and is_conv(j) and m.bias is not None and is_conv(j + 1):
                 need64 += F.stats_buffer_numel(m.out_channels)      # conv(bias) -> conv: the first one's bias gradient (epilogue sums of the second's data gradient)
         if need or need64:
-            pool = torch.zeros(need + 2 * need64, dtype=torch.float32, device=x.t.device)
+            pool = F.zeros(need + 2 * need64, torch.float32, x.t.device)
             F.register_pool(pool)
             pool64 = pool[:2 * need64].view(torch.float64)      # the float64 part first (8-byte aligned: start of the allocation)
             pool_off = 2 * need64

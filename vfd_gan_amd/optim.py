@@ -59,7 +59,7 @@ class Adam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         # the arena views must stay attached, so gradients are zeroed, never dropped
-        self.grad_arena.zero_()
+        F.zero_(self.grad_arena)
         for p, o in zip(self._params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * o:
                 p.grad = self.grad_arena[o:o + p.numel()].view(p.shape)
