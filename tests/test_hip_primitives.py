@@ -471,7 +471,7 @@ def test_losses(dt, dev):
         vd = v.to(dev).requires_grad_(name in ("l2", "l1"))
         lh = fh(F.to_cl(ud, dt), F.to_cl(vd, dt)) * 3.0
         lh.backward()
-        assert abs(float(lh) - float(lr)) < tol * max(1.0, abs(float(lr))), name
+        assert abs(float(lh.detach()) - float(lr.detach())) < tol * max(1.0, abs(float(lr.detach()))), name
         assert relerr(ud.grad, ur.grad) < max(tol, TOL[dt]), name
         if name in ("l2", "l1"):
             assert relerr(vd.grad, vr.grad) < max(tol, TOL[dt]), name

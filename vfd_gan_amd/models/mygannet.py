@@ -352,11 +352,11 @@ class MyGAN(GANBaseModel):
             e = {k: torch.stack([v.detach().float().reshape(()) for v in acc[k]]).cpu().numpy().astype(np.float64) for k in keys}
             gts_np = np.asarray(torch.stack(gts).cpu().numpy(), dtype=np.int32).flatten()
             pre_np = np.asarray(torch.stack(predicts).cpu().numpy()).flatten()
-        err_g_adv = F.weighted_sum((e["err_g_adv_s"], 1.0), (e["err_g_adv_t"], 1.0))
-        err_g = F.weighted_sum((e["err_g_adv_t"], self.args.w_adv), (e["err_g_con"], self.args.w_con))      # reference :416: temporal term only
-        err_d_real = F.weighted_sum((e["err_d_real_s"], 0.5), (e["err_d_real_t"], 0.5))
-        err_d_fake = F.weighted_sum((e["err_d_fake_s"], 0.5), (e["err_d_fake_t"], 0.5))
-        err_d = F.weighted_sum((err_d_real, 0.5), (err_d_fake, 0.5))
+        err_g_adv = e["err_g_adv_s"] + e["err_g_adv_t"]
+        err_g = e["err_g_adv_t"] * self.args.w_adv + e["err_g_con"] * self.args.w_con      # reference :416: temporal term only
+        err_d_real = (e["err_d_real_s"] + e["err_d_real_t"]) * 0.5
+        err_d_fake = (e["err_d_fake_s"] + e["err_d_fake_t"]) * 0.5
+        err_d = (err_d_real + err_d_fake) * 0.5
         saveto = self.save_root_dir if self.rank == 0 else None
         roc = evaluate(gts_np, pre_np, self.best_roc, self.epoch, saveto, metric='roc')
         pr = evaluate(gts_np, pre_np, self.best_pr, self.epoch, saveto, metric='pr')
