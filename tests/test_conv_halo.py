@@ -32,6 +32,10 @@ CASES = [
     ("t2d_k4s2_128to64_rows14", (2, 128, 14, 14), 64, 4, 2, 1, 0, True, False),   # ganomaly decoder pyramid (4 classes, 2x2 taps)
     ("t2d_k4s2_40to24", (2, 40, 13, 15), 24, 4, 2, 1, 0, True, True),
     ("t3d_k3s2_64to32", (1, 64, 3, 7, 12), 32, 3, 2, 1, 1, True, True),          # classes with 1 and 2 taps per dim
+    # <= 16 output channels on volumes: the 16-channel tile (anogan NetG's 3-channel ends, models/anogan.py:70-72)
+    ("t3d_k3s1_32to3", (1, 32, 5, 9, 18), 3, 3, 1, 1, 0, True, True),
+    ("t3d_k3s2_64to3", (1, 64, 3, 7, 12), 3, 3, 2, 1, 1, True, False),
+    ("c3d_k3_40to12", (2, 40, 4, 6, 16), 12, 3, 1, 1, 0, False, True),
     # frames under 2 x 2-tap classes (k4 s2 p1 transposed): conv_halo_rows (16 virtual rows x 16 pixels, one shared zero row
     # between frames, 4 workgroups per CU).  ganomaly's decoder / data-gradient shape; a partial channel chunk with partial
     # output channels, a 14-row period and partial width tiles; 5 frames of 13 rows (tiles span frames, 70 virtual rows)

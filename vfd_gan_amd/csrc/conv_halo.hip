@@ -639,7 +639,8 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
   if (!frames && Q0[0] < 3) return 0;              // 2-deep volumes would leave half of a 4-deep tile empty
   if (Q0[2] < 12 || Q0[1] < (frames ? 12 : 3)) return 0;
   const int TD = frames ? 1 : 4, TH = frames ? 16 : 4;
-  const int tile_c = d->Cout > 32 ? 64 : 32;
+  static const bool no16 = getenv("VFD_HALO_NO_16C") != nullptr;      // A/B switch (layer benchmarks)
+  const int tile_c = d->Cout > 32 ? 64 : (d->Cout > 16 || frames || no16) ? 32 : 16;      // 16: the 3-channel ends of the 3-D nets
   p.ny = (d->Cout + tile_c - 1) / tile_c;
   p.vP = 0;
   static const bool no_rows = getenv("VFD_HALO_NO_ROWS") != nullptr;      // A/B switch (layer benchmarks)
@@ -689,5 +690,5 @@ int vfd_conv_halo_try(const vfd_conv_desc* d, const void* x, const void* packed,
     return hipGetLastError() == hipSuccess ? 1 : -1;
   }
   if (frames) return tile_c == 64 ? launch_halo<64, 1, 16>(p, st) : launch_halo<32, 1, 16>(p, st);
-  return tile_c == 64 ? launch_halo<64, 4, 4>(p, st) : launch_halo<32, 4, 4>(p, st);
+  return tile_c == 64 ? launch_halo<64, 4, 4>(p, st) : tile_c == 32 ? launch_halo<32, 4, 4>(p, st) : launch_halo<16, 4, 4>(p, st);
 }

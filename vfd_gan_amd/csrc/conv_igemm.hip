@@ -757,7 +757,7 @@ extern "C" int vfd_conv_kernel_name(const vfd_conv_desc* d_in, int want_stats, c
     return VFD_OK;
   }
   if (halo > 0) {
-    snprintf(buf, n, "conv_halo<%s,%s>", t, dn.Cout > 32 ? "64c_x_256p" : "32c_x_256p");
+    snprintf(buf, n, "conv_halo<%s,%s>", t, dn.Cout > 32 ? "64c_x_256p" : (dn.Cout > 16 || (dn.Di == 1 && dn.Do == 1) || getenv("VFD_HALO_NO_16C") != nullptr) ? "32c_x_256p" : "16c_x_256p");
     return VFD_OK;
   }
   const int c = dn.Cout;   // launch<T>() below
