@@ -44,6 +44,11 @@ CONV_CASES = [
     ("K6_conv2d_k3_60to256_turn", (2, 60, 6, 6), 256, 3, 1, 1, 0, False, False),
     ("K6_conv2d_k7_128to130_turn", (3, 128, 7, 7), 130, 7, 1, 0, 0, False, True),
     ("K6_convT2d_k4s2_256to64_turn", (2, 256, 4, 4), 64, 4, 2, 1, 0, True, True),
+    # stride-1 layers with <= 8 output channels over >= 16 input channels: the filter gradient runs in the transposed form (x's
+    # channels as tile rows, dy gathered) and is permuted back (functional._Conv.backward `swap`): mygan's conv_last shape, 2-D, k1
+    ("K1_conv3d_last_32to1_k3", (2, 32, 4, 10, 12), 1, 3, 1, 1, 0, False, True),
+    ("K6_conv2d_k3_24to3_swap", (2, 24, 9, 11), 3, 3, 1, 1, 0, False, False),
+    ("K4_conv3d_k133_40to5_swap", (1, 40, 3, 8, 10), 5, (1, 3, 3), 1, (0, 1, 1), 0, False, True),
     # 517 tiles of 128c x 256p on 512 workgroup slots (more than one round of workgroups, XCD-ordered ids)
     ("K6_conv2d_k1_517tiles", (3, 8, 210, 210), 128, 1, 1, 0, 0, False, True),
     # thin-channel pyramid ends (bf16: conv_small.hip; f32: implicit GEMM) and their data gradients

@@ -653,7 +653,17 @@ class _Conv(torch.autograd.Function):
                 else:
                     _conv_launch(desc, gy, packed, None, gx, mul=(x,) + ctx.in_act if ctx.in_act is not None else None, bn=ctx.in_bn)
         if ctx.needs_input_grad[1] and not frozen:
-            desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
+            # A stride-1 convolution IS a transposed convolution with the taps reversed and padding k-1-p, whose filter is
+            # w'[ci][co][t] = w[co][ci][T-1-t].  The filter-gradient kernel keeps ONE operand's channels as tile rows (64 at least) and
+            # gathers the other tap by tap: for a layer with <= 8 output channels (mygan's conv_last, 32 -> 1: models/mygannet.py:70)
+            # the regular form pads dy's 1 channel to a 64-row tile (1.83 ms for 11 GFLOP); in the transposed form the rows are x's
+            # channels and dy is the gathered side, a quarter of the padded work.  The slabs then hold dw', permuted back below.
+            swap = (not transposed and s == (1, 1, 1) and cpad(Cout) <= 8 and cpad(Cin) > 8 and dt == torch.bfloat16
+                    and all(k[i] - 1 - p[i] >= 0 for i in range(3)))
+            if swap:
+                desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, tuple(k[i] - 1 - p[i] for i in range(3)), True, dt)
+            else:
+                desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, p, transposed, dt)
             nsplit = ctypes.c_int32()
             nbytes = ctypes.c_size_t()
             check(lib.vfd_wgrad_workspace(ctypes.byref(desc), ctypes.byref(nsplit), ctypes.byref(nbytes)), "wgrad_workspace")
@@ -679,7 +689,15 @@ class _Conv(torch.autograd.Function):
                     buf = ctypes.create_string_buffer(64)
                     check(lib.vfd_wgrad_kernel_name(ctypes.byref(desc), buf, 64), "wgrad_kernel_name")
                     timer.records.append((buf.value.decode(), _conv_flops(desc), e0, e1, _geom_str(desc)))
-                if direct is not None and bdirect is not None:
+                if swap:
+                    tw = torch.empty((Cin, Cout, T), dtype=torch.float32, device=x.device)
+                    check(lib.vfd_wgrad_reduce(ctypes.byref(desc), ws.data_ptr(), tw.data_ptr(), 0.0, stream()), "wgrad_reduce")
+                    gsw = tw.flip(2).permute(1, 0, 2).reshape(weight.shape)      # dw[co][ci][t] = dw'[ci][co][T-1-t]  (864 floats)
+                    if direct is not None:
+                        direct.add_(gsw)
+                    else:
+                        gw = gsw.contiguous()
+                elif direct is not None and bdirect is not None:
                     # the BatchNorm that consumes this conv's output left the column sums of its dx (= this layer's bias
                     # gradient) in replica rows: folded by the same launch
                     check(lib.vfd_wgrad_reduce_bias(ctypes.byref(desc), ws.data_ptr(), direct.data_ptr(), 1.0, tok["rep"].data_ptr(),
