@@ -658,8 +658,15 @@ class _Conv(torch.autograd.Function):
             # gathers the other tap by tap: for a layer with <= 8 output channels (mygan's conv_last, 32 -> 1: models/mygannet.py:70)
             # the regular form pads dy's 1 channel to a 64-row tile (1.83 ms for 11 GFLOP); in the transposed form the rows are x's
             # channels and dy is the gathered side, a quarter of the padded work.  The slabs then hold dw', permuted back below.
-            swap = (not transposed and s == (1, 1, 1) and cpad(Cout) <= 8 and cpad(Cin) > 8 and dt == torch.bfloat16
-                    and all(k[i] - 1 - p[i] >= 0 for i in range(3)))
+            # Generally: padded tile area (64-row x 128-column granularity) of the two orientations; the transposed form is taken
+            # when it is under 0.7 of the regular one (also mygan's 86 -> 32 (3,1,1) factor: 64 x 384 against 128 x 128) and the layer
+            # is not one of conv_wgrad_halo's.
+            swap = False
+            if (not transposed and s == (1, 1, 1) and dt == torch.bfloat16 and all(k[i] - 1 - p[i] >= 0 for i in range(3))
+                    and not (k[1] == 3 and k[2] == 3 and Cin >= 33 and Cout >= 33)):
+                def area(a, b):
+                    return 64 * ((a + 63) // 64) * 128 * ((T * cpad(b) + 127) // 128)
+                swap = area(Cin, Cout) < 0.7 * area(Cout, Cin)
             if swap:
                 desc = _make_desc(N, in_dhw, Cin, out_dhw, Cout, k, s, tuple(k[i] - 1 - p[i] for i in range(3)), True, dt)
             else:
