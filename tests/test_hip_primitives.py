@@ -796,14 +796,15 @@ def test_conv_to_conv_bias_gradient_from_data_gradient_statistics(dev):
     assert relerr(mine[0].bias.grad, ref[0].bias.grad) < tol and relerr(mine[1].bias.grad, ref[1].bias.grad) < tol
 
 
-@pytest.mark.parametrize("dt,ratio", [(torch.float32, 100.0), (torch.bfloat16, 30.0)], ids=["f32_100", "bf16_30"])
+@pytest.mark.parametrize("dt,ratio", [(torch.float32, 100.0), (torch.float32, 1000.0), (torch.bfloat16, 30.0), (torch.bfloat16, 300.0)],
+                         ids=["f32_100", "f32_1000", "bf16_30", "bf16_300"])
 def test_batchnorm_epilogue_statistics_large_mean_over_sigma(dt, ratio, dev):
     """|mean| / sigma >> 1 on the conv-epilogue-sums path: conv(bias = ratio * sigma) ->
     BatchNorm -> LeakyReLU with the statistics summed in the conv epilogue.  The variance is E[x^2] - mean^2: float32 sums
-    lose ratio^2 digits there (mygan's SDisc on the sparse 0/1 mask sits at ~30 and was off by 5e-3 in its loss), so the
-    epilogues add their per-wave partial sums (64 pixels, float32) in DOUBLE (include/vfdgan_hip.h vfd_conv_forward): the
-    variance keeps a relative error of ~2.4e-7 ratio^2 / sqrt(number of wave partials) — 4e-4 here (36 partials), 3e-6 on a
-    400k-pixel layer at a ratio of 30; with float32 atomics all the way (rounds 1-2) it was ~1e-6 ratio^2.  Checked against float64 BatchNorm of
+    lose ratio^2 digits there (mygan's SDisc on the sparse 0/1 mask sits at ~30 and was off by 5e-3 in its loss; with float32
+    atomics all the way, rounds 1-2, the error was ~1e-6 ratio^2).  The epilogues therefore sum SHIFTED values (t - c, c = the
+    channel's value in the tile's first row) in float32 and form the raw sums per workgroup in double (conv_epilogue.hpp): the
+    variance no longer depends on the ratio — 1e3 (VERDICT r02's request) passes the same 2e-4 gate as 100.  Checked against float64 BatchNorm of
     the stored conv output: running variance, forward, and the backward's re-associated apply pass (dx = g A + x B + D).
     (bf16 storage itself resolves a tensor only to 2^-9 |mean|: a ratio of 30 leaves sigma / 17 of rounding noise in x.)"""
     import vfd_gan_amd.nn as vnn

@@ -15,9 +15,9 @@ struct EpiP {
   void* y;
   const float* bias;
   double* stats;         // [VFD_STATS_REPLICAS][2][Cop] DOUBLES or null: per-channel sum / sum of squares of (conv + bias) for the
-                         // BatchNorm that follows.  Summed in double from the float32 accumulators on: the variance is later
-                         // formed as E[x^2] - mean^2, which in float32 sums loses |mean|/sigma squared digits (a bias-dominated
-                         // layer on a sparse input - mygan's SDisc on the 0/1 mask - has |mean|/sigma ~ 30: measured 5e-3 on its loss)
+                         // BatchNorm that follows.  The variance is later formed as E[x^2] - mean^2, which in float32 sums loses
+                         // |mean|/sigma squared digits (a bias-dominated layer on a sparse input - mygan's SDisc on the 0/1 mask -
+                         // has |mean|/sigma ~ 30: measured 5e-3 on its loss): see the shifted sums below
   int Cop, Cout;
   int act;
   float slope;
@@ -50,11 +50,17 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // 16 pixels x 32 bytes per store instruction; transposed through the (now idle) staging ring every lane stores 16
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
   typedef typename std::conditional<BN, float, double>::type S;      // accumulation type of the per-channel sums (BN hand-over: float)
-  // statistics: the WAVES_P pixel-waves of a channel add their partials into ONE double per channel with LDS atomics
-  // ([2][TILE_C] doubles: with a slot per wave the doubles pushed the 128-channel tile's epilogue into two passes, +3.5 % on
-  // its launches); the BN hand-over keeps its float slot per wave (its two passes accumulate into their own slots)
+  // statistics (ATOM): SHIFTED sums.  Per channel the workgroup picks a shift c (the value of its first tile row) and adds up
+  // d = t - c and d^2 — small numbers whatever |mean| / sigma is — in float32: registers, 16-lane shuffles, one LDS float atomic
+  // per channel and wave into [2][TILE_C] floats.  ONE thread per channel then forms the raw sums in double,
+  //   sum t = S1 + n c,   sum t^2 = S2 + 2 c S1 + n c^2      (n = valid rows of the tile),
+  // and adds them to the replica row (global double atomics), from where everything stays double.  (Round 3 history: float32
+  // sums of t, t^2 lost (|mean|/sigma)^2 digits: 5e-3 on a loss at a ratio of 30; double from the wave level on held a ratio
+  // of 100 at the price of double LDS atomics; this form holds 1e3 and beyond — the test pins it — for less work.)
+  // The BN hand-over keeps its float slot per wave (its two passes accumulate into their own slots).
   constexpr bool ATOM = !BN;
   constexpr int RED_BYTES = ATOM ? 2 * TILE_C * (int)sizeof(S) : 2 * TILE_C * WAVES_P * (int)sizeof(S);
+  static_assert(!ATOM || 3 * TILE_C * 4 + 16 <= RED_BYTES, "shift row + counter share the sums' LDS");
     // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
   constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
                      : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
@@ -66,7 +72,10 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // BatchNorm partial sums: lanes -> wave (shuffles) -> workgroup (LDS) -> ONE float atomic per channel and workgroup
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
   // same 2*Cout addresses; bn_from_sums folds the replicas).
-  S* red = reinterpret_cast<S*>(smem + OUT_BYTES);     // [2][TILE_C][WAVES_P]
+  S* red = reinterpret_cast<S*>(smem + OUT_BYTES);     // BN hand-over: [2][TILE_C][WAVES_P] floats
+  float* redf = reinterpret_cast<float*>(smem + OUT_BYTES);      // ATOM: [2][TILE_C] shifted sums | [TILE_C] shifts | valid-row count
+  float* cshift = redf + 2 * TILE_C;
+  int* nvalid = reinterpret_cast<int*>(cshift + TILE_C);
   long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
   long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
   bool pvalid[NJ];
@@ -83,8 +92,25 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   }
   if constexpr (ATOM) {
     if (want_stats) {
-      for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) red[t] = 0;
-      __syncthreads();      // zeroed before the first wave adds
+      for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) redf[t] = 0.f;
+      if (tid == 0) *nvalid = 0;
+      if (wave / WAVES_C == 0 && (lane & 15) == 0) {      // the shift of a channel: its value in tile row 0 (any value would do)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = n0 + wave_c0 + i * 16 + cq + r;
+            const float b = (p.bias != nullptr && c < p.Cout) ? p.bias[c] : 0.f;
+            cshift[wave_c0 + i * 16 + cq + r] = (SCALED ? acc[i][0][r] * p.oscale : acc[i][0][r]) + b;
+          }
+      }
+      if (wave % WAVES_C == 0) {      // valid tile rows: lanes 0..15 hold a sub-tile's 16 rows
+        int nv = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) nv += __popcll(__ballot(pvalid[j]) & 0xffffull);
+        if (lane == 0) atomicAdd(nvalid, nv);
+      }
+      __syncthreads();      // zeroed, shifts and count in place before the first wave adds
     }
   }
   // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
@@ -105,6 +131,13 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
       // 128-channel tile's launch — and the per-wave partials go to double: LDS fold, atomics, the BatchNorm fold.  Relative
       // error of the variance ~ 2.4e-7 (|mean|/sigma)^2 / sqrt(number of wave partials): 3e-6 at a ratio of 30 over 400k pixels)
       float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      float c4[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (ATOM) {
+        if (H == 0 && want_stats) {
+          const float4 cv = *reinterpret_cast<const float4*>(cshift + wave_c0 + i * 16 + cq);
+          c4[0] = cv.x; c4[1] = cv.y; c4[2] = cv.z; c4[3] = cv.w;
+        }
+      }
       // BatchNorm hand-over: xh = x * ka + kb, z = xh * kg + kt for this lane's 4 channels; the producer BatchNorm's input
       // x at this lane's (pixel, 4 channels) positions, all loads of the pass in flight before the first use
       float ka[4], kb[4], kg[4], kt[4];
@@ -143,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float t = (SCALED ? acc[i][j][r] * p.oscale : acc[i][j][r]) + b4[r];
-            if (H == 0 && want_stats && pvalid[j]) { s1[r] += t; s2[r] += t * t; }
+            if (H == 0 && want_stats && pvalid[j]) { const float dshift = t - c4[r]; s1[r] += dshift; s2[r] = __builtin_fmaf(dshift, dshift, s2[r]); }      // (explicit fma: the build runs with -ffp-contract=off)
             v[r] = ((c + r) < p.Cout) ? actf(t) : 0.f;   // pad channels stay zero (sigmoid(0) != 0)
           }
         }
@@ -181,8 +214,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           if ((lane & 15) == 0) {
             const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
             if constexpr (ATOM) {
-              atomicAdd(red + cl, a);                      // ds_add_f64
-              atomicAdd(red + TILE_C + cl, b);
+              atomicAdd(redf + cl, af);                    // ds_add_f32
+              atomicAdd(redf + TILE_C + cl, bf);
             } else {
               if (H != 0) {        // the hand-over sums are taken as the sub-tiles are emitted: pass 1 adds to pass 0 (same lane)
                 a += red[cl * WAVES_P + (wave / WAVES_C)];
@@ -264,19 +297,25 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
     }
   }
   if (want_stats) {
-    S* rep;
-    if constexpr (BN) rep = p.mul.bn_sums + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
-    else rep = p.stats + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
-    for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
-      const int which = t / TILE_C, cl = t - which * TILE_C;
-      S v = 0;
-      if constexpr (ATOM) {
-        v = red[t];
-      } else {
+    if constexpr (ATOM) {
+      double* rep = p.stats + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+      const double n = (double)*nvalid;
+      for (int cl = tid; cl < TILE_C; cl += 64 * NWAVES) {
+        if (n0 + cl < p.Cout) {
+          const double c = (double)cshift[cl], s1 = (double)redf[cl], s2 = (double)redf[TILE_C + cl];
+          atomicAdd(rep + n0 + cl, s1 + n * c);                                  // global_atomic_add_f64: two per channel and workgroup
+          atomicAdd(rep + p.Cop + n0 + cl, s2 + 2.0 * c * s1 + n * c * c);
+        }
+      }
+    } else {
+      S* rep = p.mul.bn_sums + (size_t)(stats_replica % VFD_STATS_REPLICAS) * 2 * p.Cop;
+      for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) {
+        const int which = t / TILE_C, cl = t - which * TILE_C;
+        S v = 0;
 #pragma unroll
         for (int w = 0; w < WAVES_P; ++w) v += red[t * WAVES_P + w];
+        if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);      // global_atomic_add_f32: one per channel and workgroup
       }
-      if (n0 + cl < p.Cout) atomicAdd(rep + which * p.Cop + n0 + cl, v);      // global_atomic_add_f32 / _f64: one per channel and workgroup
     }
   }
 }
