@@ -103,9 +103,10 @@ int vfd_pack_filters(const int64_t* jobs_dev, int njobs, int64_t total_blocks, v
 /* y = act(conv(x, packed) + bias).  `bias` float32[Cout] or NULL.
  * When stats != NULL (float64 [VFD_STATS_REPLICAS][2][CPAD(Cout)], pre-zeroed) the epilogue also accumulates
  * the per-channel sum and sum of squares of the pre-activation output (BatchNorm batch statistics,
- * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106), summed in DOUBLE from the float32
- * accumulators on (the variance is formed as E[x^2] - mean^2: float32 sums lose (|mean|/sigma)^2 digits there), one
- * atomic per channel and workgroup, spread over replica rows; vfd_bn_stats_from_sums / vfd_bn_act_forward_sums fold them. */
+ * models/spatiotempconv.py:51, models/mygannet.py:19, models/ganomaly.py:46,56,97,106).  The variance is later formed as
+ * E[x^2] - mean^2, where float32 sums lose (|mean|/sigma)^2 digits: a workgroup sums SHIFTED values (x - c, c = the channel's
+ * value in its first tile row) in float32 and adds the raw sums, formed in double, to one of the replica rows with one double
+ * atomic per channel and sum; vfd_bn_stats_from_sums / vfd_bn_act_forward_sums fold the rows (in double). */
 #define VFD_STATS_REPLICAS 8
 int vfd_conv_forward(const vfd_conv_desc* d, const void* x, const void* packed, const float* bias, void* y,
                      double* stats, size_t stats_bytes, void* ws, size_t ws_bytes, void* stream);
