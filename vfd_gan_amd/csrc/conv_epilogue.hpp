@@ -25,6 +25,12 @@ struct EpiP {
   float oscale;          // SCALED kernels (fp8 operands): the accumulator is multiplied by this first (1 / (scale_x * scale_w))
 };
 
+// LDS bytes of the statistics block behind the output image: shifted sums [2][TILE_C][WAVES_P] floats + shifts [TILE_C] + the
+// valid-row counter (the BatchNorm hand-over: [2][TILE_C][WAVES_P] floats)
+constexpr int epi_red_bytes(int tile_c, int waves_p, bool bn) {
+  return bn ? 2 * tile_c * waves_p * 4 : (2 * waves_p + 1) * tile_c * 4 + 16;
+}
+
 template <typename T, int WAVES_C, int WAVES_P, int NI, int NJ, int RING_BYTES, bool BN, bool SCALED, typename OutOff, typename RowValid>
 __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], const EpiP& p, int n0, int stats_replica,
                                               OutOff out_offset, RowValid row_valid) {
@@ -51,16 +57,17 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // bytes and an instruction covers whole pixel rows of the tile (128..512 contiguous bytes each).
   typedef typename std::conditional<BN, float, double>::type S;      // accumulation type of the per-channel sums (BN hand-over: float)
   // statistics (ATOM): SHIFTED sums.  Per channel the workgroup picks a shift c (the value of its first tile row) and adds up
-  // d = t - c and d^2 — small numbers whatever |mean| / sigma is — in float32: registers, 16-lane shuffles, one LDS float atomic
-  // per channel and wave into [2][TILE_C] floats.  ONE thread per channel then forms the raw sums in double,
+  // d = t - c and d^2 — small numbers whatever |mean| / sigma is — in float32: registers, 16-lane shuffles, then ONE SLOT per
+  // channel and pixel-wave in LDS (no LDS float atomics: their arrival order would make the sums, and through BatchNorm and
+  // Adam the whole run, differ from launch to launch; a first version did and test_graph_replay_after_reinit_d caught it).
+  // ONE thread per channel then adds the slots in wave order and forms the raw sums in double,
   //   sum t = S1 + n c,   sum t^2 = S2 + 2 c S1 + n c^2      (n = valid rows of the tile),
   // and adds them to the replica row (global double atomics), from where everything stays double.  (Round 3 history: float32
   // sums of t, t^2 lost (|mean|/sigma)^2 digits: 5e-3 on a loss at a ratio of 30; double from the wave level on held a ratio
   // of 100 at the price of double LDS atomics; this form holds 1e3 and beyond — the test pins it — for less work.)
   // The BN hand-over keeps its float slot per wave (its two passes accumulate into their own slots).
   constexpr bool ATOM = !BN;
-  constexpr int RED_BYTES = ATOM ? 2 * TILE_C * (int)sizeof(S) : 2 * TILE_C * WAVES_P * (int)sizeof(S);
-  static_assert(!ATOM || 3 * TILE_C * 4 + 16 <= RED_BYTES, "shift row + counter share the sums' LDS");
+  constexpr int RED_BYTES = epi_red_bytes(TILE_C, WAVES_P, BN);
     // the tile goes through in NH passes (half of every wave's pixel sub-tiles each) when it does not fit in one (256 x 256: 128 KiB)
   constexpr int NH = (TILE_P * TILE_C * 2 + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 1
                      : ((NJ % 2 == 0 && TILE_P * TILE_C + RED_BYTES + TILE_P * 8 <= RING_BYTES) ? 2 : 0);
@@ -73,8 +80,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   // into one of VFD_STATS_REPLICAS replica rows (spreads the contention of thousands of workgroups adding into the
   // same 2*Cout addresses; bn_from_sums folds the replicas).
   S* red = reinterpret_cast<S*>(smem + OUT_BYTES);     // BN hand-over: [2][TILE_C][WAVES_P] floats
-  float* redf = reinterpret_cast<float*>(smem + OUT_BYTES);      // ATOM: [2][TILE_C] shifted sums | [TILE_C] shifts | valid-row count
-  float* cshift = redf + 2 * TILE_C;
+  float* redf = reinterpret_cast<float*>(smem + OUT_BYTES);      // ATOM: [2][TILE_C][WAVES_P] shifted sums | [TILE_C] shifts | valid-row count
+  float* cshift = redf + 2 * TILE_C * WAVES_P;
   int* nvalid = reinterpret_cast<int*>(cshift + TILE_C);
   long long* orow = reinterpret_cast<long long*>(smem + OUT_BYTES + RED_BYTES);   // [TILE_P] output offset of a tile row, or -1
   long long opix[NJ];     // direct path: output pixel offset in elements (pixel * Cop), or -1
@@ -92,7 +99,6 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
   }
   if constexpr (ATOM) {
     if (want_stats) {
-      for (int t = tid; t < 2 * TILE_C; t += 64 * NWAVES) redf[t] = 0.f;
       if (tid == 0) *nvalid = 0;
       if (wave / WAVES_C == 0 && (lane & 15) == 0) {      // the shift of a channel: its value in tile row 0 (any value would do)
 #pragma unroll
@@ -110,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
         for (int j = 0; j < NJ; ++j) nv += __popcll(__ballot(pvalid[j]) & 0xffffull);
         if (lane == 0) atomicAdd(nvalid, nv);
       }
-      __syncthreads();      // zeroed, shifts and count in place before the first wave adds
+      __syncthreads();      // shifts and count in place before the first wave reads them
     }
   }
   // pass h of NH emits the pixel sub-tiles j in [h*NJ/NH, (h+1)*NJ/NH) of EVERY wave (so that no wave carries its whole
@@ -214,8 +220,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           if ((lane & 15) == 0) {
             const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile
             if constexpr (ATOM) {
-              atomicAdd(redf + cl, af);                    // ds_add_f32
-              atomicAdd(redf + TILE_C + cl, bf);
+              redf[cl * WAVES_P + (wave / WAVES_C)] = af;      // this wave's slot
+              redf[(TILE_C + cl) * WAVES_P + (wave / WAVES_C)] = bf;
             } else {
               if (H != 0) {        // the hand-over sums are taken as the sub-tiles are emitted: pass 1 adds to pass 0 (same lane)
                 a += red[cl * WAVES_P + (wave / WAVES_C)];
@@ -302,7 +308,10 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
       const double n = (double)*nvalid;
       for (int cl = tid; cl < TILE_C; cl += 64 * NWAVES) {
         if (n0 + cl < p.Cout) {
-          const double c = (double)cshift[cl], s1 = (double)redf[cl], s2 = (double)redf[TILE_C + cl];
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int w = 0; w < WAVES_P; ++w) { s1 += (double)redf[cl * WAVES_P + w]; s2 += (double)redf[(TILE_C + cl) * WAVES_P + w]; }
+          const double c = (double)cshift[cl];
           atomicAdd(rep + n0 + cl, s1 + n * c);                                  // global_atomic_add_f64: two per channel and workgroup
           atomicAdd(rep + p.Cop + n0 + cl, s2 + 2.0 * c * s1 + n * c * c);
         }

@@ -65,7 +65,7 @@ struct HaloCfg {
   static constexpr int HALO_BYTES = (ROWS_MAX + 15) / 16 * 1024;
   static constexpr int FTAP = TILE_C * 64;                    // one tap's filter slice
   static constexpr int FSTAGE = 3 * FTAP;                     // the (up to 3) w-taps of one (kd, kh)
-  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + 2 * TILE_C * 4 * 4 + 256 * 8;      // output rows + per-channel sums ([2][TILE_C] doubles, or the hand-over's [2][TILE_C][4] floats) + row offsets
+  static constexpr int EPI_BYTES = 256 * TILE_C * 2 + epi_red_bytes(TILE_C, 4, false) + 256 * 8;      // output rows + statistics block (conv_epilogue.hpp) + row offsets
   static constexpr int NFS = 2;                               // filter ring depth
   static constexpr int LDS = (HALO_BYTES + NFS * FSTAGE > EPI_BYTES) ? HALO_BYTES + NFS * FSTAGE : EPI_BYTES;
   static constexpr int NHW = ((ROWS_MAX + 15) / 16 + 3) / 4;  // halo DMA instructions per wave (upper bound)
@@ -330,7 +330,7 @@ struct RowsCfg {
   static constexpr int FSTAGE = KMAX * FTAP;
   static constexpr int NFS = 2;
   static constexpr int TILE_P = 16 * WB;
-  static constexpr int EPI_BYTES = TILE_P * TILE_C * 2 + 2 * TILE_C * 8 + TILE_P * 8;
+  static constexpr int EPI_BYTES = TILE_P * TILE_C * 2 + epi_red_bytes(TILE_C, NW, false) + TILE_P * 8;
   static constexpr int LDS = (NHB * HALO_BYTES + NFS * FSTAGE > EPI_BYTES) ? NHB * HALO_BYTES + NFS * FSTAGE : EPI_BYTES;
   static constexpr int NHW = (NHI + NW - 1) / NW;             // halo DMA instructions per wave
   static constexpr int NFW = (KMAX * NI + NW - 1) / NW;       // filter DMA instructions per wave and stage
