@@ -501,7 +501,7 @@ int pick_ksplit(const ConvP& p, long long M, int bk) {
   if (blocks >= 128 || nsteps < 32) return 1;
   long long ks = 512 / blocks;
   if (ks > nsteps / 8) ks = nsteps / 8;
-  if (ks > 64) ks = 64;
+  if (ks > 32) ks = 32;      // (swept 8..256 on ganomaly's 7 x 7 -> 1 x 1 layers, round 3: 58 / 39 / 32.5 / 36 / 44 / 44 us at 8 / 16 / 32 / 64 / 128 / 256)
   return ks < 2 ? 1 : (int)ks;
 }
 
