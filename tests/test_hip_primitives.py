@@ -492,6 +492,34 @@ def test_losses(dt, dev):
         assert abs(float(lh) - float(lr)) < 1e-6 and relerr(pd.grad, prr.grad) < 1e-5
 
 
+def test_zero_fill_and_loss_term_arithmetic(dev):
+    """vfd_zero (any byte count, 16-byte-aligned base) and vfd_weighted_sum4 / vfd_scale4: the torch expression they replace,
+    `a * w0 + b * w1 + c * w2` (float32, left to right, no fused multiply-add), forward and backward, bit for bit."""
+    from vfd_gan_amd import functional as F
+    for n in (1, 3, 4, 5, 1000, 4099):
+        t = torch.full((n,), 7.0, device=dev)
+        F.zero_(t)
+        assert float(t.abs().sum()) == 0.0
+        b = torch.full((n,), 3, dtype=torch.uint8, device=dev)
+        F.zero_(b)
+        assert int(b.sum()) == 0
+    g = torch.Generator().manual_seed(8)
+    for k in (1, 2, 3, 4):
+        vals = [torch.rand((), generator=g).mul(3).to(dev).requires_grad_() for _ in range(k)]
+        ws = [0.5, 50.0, 1.0, 0.37][:k]
+        out = F.weighted_sum(*zip(vals, ws))
+        ref_in = [v.detach().clone().requires_grad_() for v in vals]
+        ref = ref_in[0] * ws[0]
+        for v, w in zip(ref_in[1:], ws[1:]):
+            ref = ref + v * w
+        assert float(out.detach()) == float(ref.detach()), (k, float(out.detach()), float(ref.detach()))
+        up = torch.tensor(1.75, device=dev)
+        out.backward(up)
+        ref.backward(up)
+        for a, r in zip(vals, ref_in):
+            assert float(a.grad) == float(r.grad)
+
+
 def test_adam_matches_torch(dev):
     from vfd_gan_amd import optim as hoptim
     torch.manual_seed(0)
