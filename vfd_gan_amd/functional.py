@@ -5,7 +5,7 @@ libvfdgan_hip.so on torch's current stream.  Tensors that flow between ops are c
 ``t[N, D, H, W, Cp]`` (Cp = C rounded up to 8, pad channels zero) in the compute dtype (bfloat16 or float32),
 wrapped in :class:`ClTensor`, which remembers the logical channel count.  PyTorch supplies device memory,
 streams and the autograd tape.  The arithmetic of the hot path runs in the library's kernels; what torch's own element-wise
-kernels still do per step is bookkeeping on a few hundred floats (rocprofv3, profiles/r03_*_kernel_stats.csv: under 0.3 % of a
+kernels still do per step is bookkeeping on a few hundred floats (rocprofv3, profiles/r03_*_kernel_stats.csv: about 0.4 % of a
 step's kernel time): autograd's sum where a small tensor has two consumers, the 864-float permutation of a role-swapped filter
 gradient, the dropout / Adam step counters.  Zero fills, the sum of a fan-out's gradients and the loss-term arithmetic go
 through vfd_zero / vfd_add / vfd_weighted_sum4.
