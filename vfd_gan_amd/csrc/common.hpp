@@ -249,6 +249,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes with the same lane >> 4: the 16 pixels that hold one channel quad in the MFMA
+// accumulator layout); every lane of the row receives it.  Four rotate-and-add steps on the VALU (v_add_f32 with a DPP row_ror
+// operand) instead of the four ds_bpermute_b32 round trips through the LDS crossbar that __shfl_xor lowers to (128 of them per
+// wave and tile in the statistics epilogue).  Association: ((x_i + x_{i+8}) + (x_{i+4} + x_{i+12})) + ... — fixed.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));      // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));      // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));      // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));      // row_ror:1
+  return v;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -214,8 +214,8 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float af = s1[r], bf = s2[r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { af += __shfl_xor(af, o, 64); bf += __shfl_xor(bf, o, 64); }
+          af = row16_sum(af);
+          bf = row16_sum(bf);
           S a = (S)af, b = (S)bf;
           if ((lane & 15) == 0) {
             const int cl = wave_c0 + i * 16 + cq + r;      // channel within the tile

@@ -205,8 +205,8 @@ __global__ __launch_bounds__(64 * CIN8_WAVES, ROWS == 0 ? 4 : 3) void conv_cin8_
             const float t = pxok_t[j] ? v[(i * CIN8_NJ + j) * 4 + r] : 0.f;
             f1 += t; f2 += t * t;
           }
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); }
+          f1 = row16_sum(f1);
+          f2 = row16_sum(f2);
           const double a1 = (double)f1, a2 = (double)f2;
           if ((lane & 15) == 0) {
             atomicAdd(red_s + i * 16 + cq + r, a1);
