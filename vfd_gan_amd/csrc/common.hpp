@@ -139,8 +139,17 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+// (two single conversions + shift + or: kept for the fp8 256 x 256 tile, which sits exactly at its 128 registers and spills one
+// with the packed form below)
+__device__ __forceinline__ uint32_t pack2bf_2cvt(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  // ONE v_cvt_pk_bf16_f32 for the pair (found in the emitted ISA, round 3: the epilogues converted every value on its own)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;

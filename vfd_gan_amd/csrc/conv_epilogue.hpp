@@ -191,7 +191,9 @@ __device__ __forceinline__ void conv_epilogue(char* smem, f32x4 (&acc)[NI][NJ], 
           // 8-byte unit u of tile row (pixel) with row & 15 == n sits at slot u ^ n: the 16 rows of one ds_write_b64
           // group land on 16 different bank pairs, and a pixel's 16-byte chunk c is found whole at c ^ (n >> 1)
           const int n = lane & 15;
-          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          uint2 o;
+          if constexpr (SCALED) { o.x = pack2bf_2cvt(v[0], v[1]); o.y = pack2bf_2cvt(v[2], v[3]); }
+          else { o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); }
           *reinterpret_cast<uint2*>(smem + ((wave / WAVES_C) * (JN * 16) + (j - H * JN) * 16 + n) * (TILE_C * 2) + ((((wave_c0 + i * 16 + cq) >> 2) ^ n) << 3)) = o;
         } else {
           if (opix[j] >= 0 && c < p.Cop) {
